@@ -1,0 +1,100 @@
+"""Seeded synthetic inputs: hash families, partitioner functions, base/query sets.
+
+The reference draws its hash families from the JVM's RNG and breeze
+(AngleHashFamily.scala:37-85,121-149, PStableHashFamily.scala:37-77), which
+cannot be reproduced bit for bit; the forest therefore takes the families as
+data.  This module generates them with numpy in the same *shape*: a pool of
+`family_size` functions, `table_num` chains of `chain_length` functions pulled
+from the pool with replacement, each chain shuffled `permutation_num` times
+(angle only), and one independent `partition_bits x 32` partitioner per table
+(DensevectorRDFInit.scala:63-77).
+"""
+import numpy as np
+
+
+def make_family(dim, table_num=10, permutation_num=3, chain_length=32, family="angle",
+                family_size=100, partition_bits=3, orthogonal=True, pstable_mu=0.0,
+                pstable_sigma=1.0, pstable_w=4, seed=88387, part_seed=88388):
+    """-> dict(fns, b, w, chain_fn, part_fns, part_b, part_w, family, partition_bits)."""
+    rng = np.random.default_rng(seed)
+    if family == "angle":
+        if orthogonal:
+            # AngleHashFamily.scala:73-85: Q of a QR of a uniform random matrix.
+            m = rng.random((max(family_size, dim), dim))
+            q, _ = np.linalg.qr(m)
+            fns = np.ascontiguousarray(q[:family_size])
+        else:
+            v = rng.random((family_size, dim)) * rng.choice([-1.0, 1.0], size=(family_size, dim))
+            fns = v / np.sqrt((v * v).sum(axis=1, keepdims=True))
+        b = w = None
+        L = table_num * permutation_num
+        chain_fn = np.empty((L, chain_length), dtype=np.int32)
+        for t in range(table_num):
+            pulled = rng.integers(0, family_size, size=chain_length)
+            for p in range(permutation_num):
+                chain_fn[permutation_num * t + p] = rng.permutation(pulled)
+    elif family == "pStable":
+        fns = rng.normal(pstable_mu, pstable_sigma, size=(family_size, dim))
+        b = rng.random(family_size) * pstable_w
+        w = np.full(family_size, pstable_w, dtype=np.int32)
+        L = table_num  # PStableHashFamily.pick returns tableNum chains (PStableHashFamily.scala:68)
+        chain_fn = rng.integers(0, family_size, size=(L, chain_length)).astype(np.int32)
+    else:
+        raise ValueError(family)
+    prng = np.random.default_rng(part_seed)
+    pb = partition_bits
+    if family == "angle":
+        part_fns = np.empty((L, pb, 32))
+        for t in range(L):
+            m = prng.random((32, 32))
+            q, _ = np.linalg.qr(m)
+            part_fns[t] = q[prng.integers(0, 32, size=pb)] if pb else np.empty((0, 32))
+        part_b = part_w = None
+    else:
+        part_fns = prng.normal(pstable_mu, pstable_sigma, size=(L, pb, 32))
+        part_b = prng.random((L, pb)) * pstable_w
+        part_w = np.full((L, pb), pstable_w, dtype=np.int32)
+    return dict(family=family, fns=np.ascontiguousarray(fns, dtype=np.float64), b=b, w=w,
+                chain_fn=chain_fn, part_fns=np.ascontiguousarray(part_fns, dtype=np.float64),
+                part_b=part_b, part_w=part_w, partition_bits=pb)
+
+
+def make_gaussian_family(dim, table_num, chain_length=32, partition_bits=3, seed=88387,
+                         part_seed=88388):
+    """One distinct N(0,1) function per chain position (pool = table_num*chain_length)."""
+    rng = np.random.default_rng(seed)
+    F = table_num * chain_length
+    fns = rng.normal(size=(F, dim))
+    chain_fn = np.arange(F, dtype=np.int32).reshape(table_num, chain_length)
+    prng = np.random.default_rng(part_seed)
+    part_fns = prng.normal(size=(table_num, partition_bits, 32))
+    return dict(family="angle", fns=fns, b=None, w=None, chain_fn=chain_fn, part_fns=part_fns,
+                part_b=None, part_w=None, partition_bits=partition_bits)
+
+
+def make_clustered(n, dim, nq, n_clusters=1000, sigma=0.3, noise=0.05, seed=1234, qseed=4321,
+                   dtype=np.float32, chunk=100000):
+    """Mixture of `n_clusters` Gaussians (centres N(0,I), std `sigma`); queries are
+    base rows plus N(0, noise^2) noise.  -> (X [n,dim], Q [nq,dim], picked rows)."""
+    rng = np.random.default_rng(seed)
+    centres = rng.normal(size=(n_clusters, dim)).astype(np.float32)
+    X = np.empty((n, dim), dtype=dtype)
+    for s in range(0, n, chunk):
+        e = min(n, s + chunk)
+        lab = rng.integers(0, n_clusters, size=e - s)
+        X[s:e] = centres[lab] + sigma * rng.standard_normal((e - s, dim), dtype=np.float32)
+    qrng = np.random.default_rng(qseed)
+    pick = qrng.integers(0, n, size=nq)
+    Q = (X[pick].astype(np.float32) + noise * qrng.standard_normal((nq, dim), dtype=np.float32)).astype(dtype)
+    return X, Q, pick
+
+
+def make_sift_like(n, dim, nq, seed=99, dtype=np.float32):
+    """Integer-valued 0..255 components stored as floats (SIFT-shaped)."""
+    rng = np.random.default_rng(seed)
+    centres = rng.integers(0, 256, size=(256, dim)).astype(np.float32)
+    lab = rng.integers(0, 256, size=n)
+    X = np.clip(np.rint(centres[lab] + 12.0 * rng.standard_normal((n, dim), dtype=np.float32)), 0, 255).astype(dtype)
+    pick = rng.integers(0, n, size=nq)
+    Q = np.clip(np.rint(X[pick] + 4.0 * rng.standard_normal((nq, dim), dtype=np.float32)), 0, 255).astype(dtype)
+    return X, Q, pick

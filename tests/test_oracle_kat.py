@@ -1,0 +1,236 @@
+"""Pins the CPU oracle against the known answers the reference's own unit
+tests hold for the hot path (reference paths relative to its checkout)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+
+def dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+L = O.lib()
+
+
+def test_angle_single_function():
+    # src/test/scala/mclab/lsh/hashFamilies/AngleHashSuite.scala:10-18
+    fns = np.array([[1.0, 1.0, 1.0]])
+    v = np.array([1.0, 1.0, 1.0])
+    assert L.orc_angle_hash_dense(dp(fns), 1, 3, dp(v)) == -2147483648
+
+
+def test_angle_two_functions():
+    # AngleHashSuite.scala:20-33
+    fns = np.array([[1.0, 1.0, 1.0], [1.5, -1.0, 0.0]])
+    v = np.array([1.0, 1.0, 1.0])
+    assert L.orc_angle_hash_dense(dp(fns), 2, 3, dp(v)) == -1073741824
+
+
+def test_angle_sign_of_zero_is_zero():
+    # AngleHashFamily.scala:184 -- sign(x) = 0 iff x <= 0
+    fns = np.array([[1.0, -1.0, 0.0]])
+    v = np.array([1.0, 1.0, 1.0])
+    assert L.orc_angle_hash_dense(dp(fns), 1, 3, dp(v)) == 0
+
+
+def test_pstable_single_function():
+    # src/test/scala/mclab/lsh/hashFamilies/PStableHashSuite.scala:14-25
+    fns = np.array([[1.0, 1.0, 1.0]])
+    b = np.array([3.0])
+    w = np.array([10], dtype=np.int32)
+    v = np.array([1.0, 1.0, 1.0])
+    assert L.orc_pstable_hash_dense(dp(fns), dp(b), ip(w), 1, 3, dp(v)) == 923521
+
+
+def test_pstable_two_functions():
+    # PStableHashSuite.scala:27-41
+    fns = np.array([[1.0, 1.0, 1.0], [2.0, 2.0, 2.0]])
+    b = np.array([3.0, 3.0])
+    w = np.array([4, 4], dtype=np.int32)
+    v = np.array([1.0, 1.0, 1.0])
+    assert L.orc_pstable_hash_dense(dp(fns), dp(b), ip(w), 2, 3, dp(v)) == -1806530940
+
+
+def test_pstable_truncates_toward_zero():
+    # PStableHashFamily.scala:130 -- .toInt, not floor: (-0.5) -> 0, not -1
+    sums = np.array([-5.0])
+    b = np.array([3.0])
+    w = np.array([4], dtype=np.int32)
+    h = L.orc_pstable_hash_from_sums(dp(sums), dp(b), ip(w), 1)
+    zero = np.zeros(4, dtype=np.int8)
+    assert h == L.orc_bytes_hashcode(zero.ctypes.data_as(C.POINTER(C.c_int8)), 4) == 923521
+
+
+def test_d2i_saturates():
+    assert L.orc_d2i(float("nan")) == 0
+    assert L.orc_d2i(1e30) == 2147483647
+    assert L.orc_d2i(-1e30) == -2147483648
+    assert L.orc_d2i(-3.9) == -3 and L.orc_d2i(3.9) == 3
+
+
+def test_dot_sparse_sparse():
+    # src/test/scala/mclab/lsh/vector/SimilarityCalculatorSuite.scala:6-25
+    i1 = np.array([0, 2, 3, 9], dtype=np.int32); v1 = np.array([1.0, 0.5, 1.2, 2.5])
+    i2 = np.array([2, 3], dtype=np.int32); v2 = np.array([0.2, 1.5])
+    # SimilarityCalculatorSuite.scala:11 asserts 1.8, which contradicts the code it
+    # tests (0.5*0.2 + 1.2*1.5 = 1.9): a stale assertion, kept out of the pin set.
+    assert L.orc_dot_sparse_sparse(10, ip(i1), dp(v1), 4, ip(i2), dp(v2), 2) == 0.5 * 0.2 + 1.2 * 1.5
+    i3 = np.array([0, 2, 3, 9], dtype=np.int32); v3 = np.ones(4)
+    i4 = np.array([5, 6], dtype=np.int32); v4 = np.ones(2)
+    assert L.orc_dot_sparse_sparse(10, ip(i3), dp(v3), 4, ip(i4), dp(v4), 2) == 0.0
+    v3b = np.array([1.0, 1.0, 2.0, 1.0])
+    i5 = np.array([3, 6, 9], dtype=np.int32); v5 = np.array([1.3, 1.0, 1.0])
+    assert L.orc_dot_sparse_sparse(10, ip(i3), dp(v3b), 4, ip(i5), dp(v5), 3) == 3.6
+
+
+def test_dot_dense_exact():
+    # SimilarityCalculatorSuite.scala:26-34 -- `===` on doubles pins left-to-right fp64
+    a = np.array([0.1, 0.2, 0.3]); b = np.array([0.2, 0.3, 0.4])
+    assert L.orc_dot_dense(dp(a), dp(b), 3) == 0.2
+    f = np.array([1.1, 1.2, 1.3])
+    assert L.orc_dot_dense(dp(f), dp(a), 3) == 0.74
+
+
+@pytest.mark.parametrize("dns", [32, 64, 128])
+def test_dir_offset_from_slot_is_bitmap_rank(dns):
+    # src/test/java/mclab/mapdb/RandomDrawTreeMapTest.java:631-685 (slot_to_offset_int)
+    rng = np.random.default_rng(7)
+    words = dns // 32
+    for _ in range(1000):
+        bm = rng.integers(-2**31, 2**31, size=words, dtype=np.int64).astype(np.int32)
+        bits = [(int(np.uint32(bm[j])) >> k) & 1 for j in range(words) for k in range(32)]
+        offset = words
+        for slot in range(dns):
+            c = L.orc_dir_offset_from_slot(ip(bm), slot, dns)
+            if bits[slot] == 0:
+                c = -c
+            assert c == offset
+            offset += bits[slot]
+
+
+def _const_hash_index(B, dns=128, bucket_bits=28, pb=0):
+    # every vector hashes to 0x80000000: function 0 = +e0, the other 31 = -e0
+    fns = np.array([[1.0], [-1.0]])
+    chain = np.array([[0] + [1] * 31], dtype=np.int32)
+    p = dict(family="angle", fns=fns, chain_fn=chain, part_fns=np.zeros((1, pb, 32)),
+             partition_bits=pb, bucket_bits=bucket_bits, dir_node_size=dns, bucket_overflow=B,
+             exclude_self="never")
+    return O.OracleIndex(p)
+
+
+def test_hash_dir_expand():
+    # RandomDrawTreeMapTest.java:185-285: BUCKET_OVERFLOW keys with one hash stay a
+    # chain (newest first); one more turns the slot into a directory whose child
+    # chain lists the keys oldest first.
+    B = 4
+    ix = _const_hash_index(B)
+    one = np.array([[1.0]])
+    for i in range(B):
+        ix.fit(one, threads=1)
+    assert ix.hash(0, one[0]) == -2147483648
+    dn, lv, mx = ix.table_stats(0)
+    assert (dn, lv, mx) == (16, 1, B)
+    got = ix.get_similar(0, -1, one[0], 0)
+    # dirNodeSize 128: root level uses bits 21..27, flips of bits 0..20 stay in the chain
+    assert got.reshape(21, B).tolist() == [[3, 2, 1, 0]] * 21
+    ix.fit(one, threads=1)
+    dn, lv, mx = ix.table_stats(0)
+    assert (dn, lv, mx) == (17, 1, B + 1)
+    got = ix.get_similar(0, -1, one[0], 0)
+    assert got.reshape(14, B + 1).tolist() == [[0, 1, 2, 3, 4]] * 14
+    assert ix.misflag_events == 0
+    # a further key splits again (born-full chain of B+1, then one more arrival)
+    ix.fit(one, threads=1)
+    assert ix.table_stats(0) == (18, 1, B + 2)
+
+
+@pytest.mark.parametrize("dns,bb,levels", [(128, 28, 4), (64, 30, 5), (32, 30, 6), (32, 28, 5)])
+def test_directory_node_sizes(dns, bb, levels):
+    # src/test/java/mclab/mapdb/DirectoryNodeSuite.java:23-113 uses these
+    # (bucketBits, dirNodeSize) pairs; the trie depth follows RDT:456.
+    ix = _const_hash_index(2, dns=dns, bucket_bits=bb)
+    one = np.array([[1.0]])
+    for i in range(2 + levels + 3):
+        ix.fit(one, threads=1)
+    dn, lv, mx = ix.table_stats(0)
+    seg = 1 << (32 - bb)
+    # chain splits once per level until level 0, where it grows without bound
+    assert dn == seg + (levels - 1)
+    assert lv == 1 and mx == 2 + levels + 3
+
+
+def test_probe_count_and_steps():
+    # RDT:753 and RDT:613-621
+    assert L.orc_probe_count(-1) == 28
+    assert L.orc_probe_count(-2147483648) == 28
+    assert L.orc_probe_count(0x7fffffff) == 27
+    assert L.orc_probe_count(16) == 1
+    assert L.orc_probe_count(8) == 0
+    assert L.orc_probe_count(7) == -1
+    assert L.orc_probe_count(0) == -4
+    out = np.empty(8, dtype=np.int32); n = C.c_int32()
+    L.orc_step_sub_indexes(5, 1, 8, ip(out), C.byref(n))
+    assert out[:n.value].tolist() == [1, 4, 5, 7]
+    L.orc_step_sub_indexes(5, 0, 8, ip(out), C.byref(n))
+    assert out[:n.value].tolist() == [5]
+    L.orc_step_sub_indexes(5, 3, 8, ip(out), C.byref(n))
+    assert out[:n.value].tolist() == list(range(8))
+
+
+def test_self_exclusion_integer_cache():
+    # RDT:982 compares boxed Integers by reference: only ids in [-128,127] are dropped
+    B = 500
+    fns = np.array([[1.0], [-1.0]])
+    chain = np.array([[0] + [1] * 31], dtype=np.int32)
+    p = dict(family="angle", fns=fns, chain_fn=chain, part_fns=np.zeros((1, 0, 32)),
+             partition_bits=0, dir_node_size=32, bucket_overflow=B, exclude_self="compat")
+    ix = O.OracleIndex(p)
+    X = np.ones((300, 1))
+    ix.fit(X, threads=1)
+    off, ids = ix.query_batch(np.array([5, 127, 128, 299]), np.ones((4, 1)), steps=0)
+    sets = [set(ids[off[i]:off[i + 1]].tolist()) for i in range(4)]
+    allids = set(range(300))
+    assert sets[0] == allids - {5}
+    assert sets[1] == allids - {127}
+    assert sets[2] == allids
+    assert sets[3] == allids
+
+
+def test_continue_bits_count_examples():
+    nb = np.array([6, 4, 2, 1], dtype=np.int32)
+    # no set bits below bit 28: only the seg nibble survives
+    assert L.orc_continue_bits_count(np.int32(-2147483648), ip(nb)) == np.int32(-2147483648)
+    # low 28 bits all ones: one run of 28 >= 6 -> every counter = 1
+    key = 0x0fffffff
+    assert L.orc_continue_bits_count(key, ip(nb)) == (1 << 21) + (1 << 14) + (1 << 7) + 1
+    # runs: 1 (bit0), 2 (bits 2-3), 4 (bits 5-8), 6 (bits 10-15)
+    key = 0b1111110111101101
+    # a0 (>=6) = 1; a1 (>=4) = 2; a2 (>=2) = 3; a3 (>=1) = 4
+    assert L.orc_continue_bits_count(key, ip(nb)) == (4 << 21) + (3 << 14) + (2 << 7) + 1
+
+
+def test_sampling_is_a_bit_permutation():
+    si = np.empty(32, dtype=np.int32)
+    L.orc_scala_shuffle_0_31(88387, ip(si))
+    assert sorted(si.tolist()) == list(range(32))
+    for j in range(32):
+        key = C.c_int32((1 << int(si[j])) & 0xffffffff).value
+        assert L.orc_sampling_one_key(key, ip(si)) & 0xffffffff == 1 << (31 - j)
+
+
+def test_angle_new_method_thresholds_have_margin():
+    # the 29 possible angles (one per popcount of the low 28 bits) sit well away
+    # from the integer thresholds, so libm differences cannot move a key
+    th = [16.0, 25.0, 33.0, 39.0, 46.0, 52.0, 58.0, 66.0, 72.0]
+    for pc in range(1, 29):
+        a = L.orc_angle_distance((1 << pc) - 1)
+        assert min(abs(a - t) for t in th) > 1e-6
+    assert np.isnan(L.orc_angle_distance(0))
+    assert L.orc_angle_new_method(0) == 0
