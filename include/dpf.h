@@ -1,0 +1,169 @@
+/*
+ * dpf.h -- C ABI of the MI355X Dynamic Partition Forest batch-query engine.
+ *
+ * This is the drop-in boundary for the reference's batch-query hot path
+ * (LSH projection -> forest bucket probe -> candidate rerank / top-k).  Every
+ * entry point names the reference interface it replaces; reference paths are
+ * relative to the reference checkout:
+ *
+ *   Dense  src/main/scala/mclab/deploy/DensevectorRDFInit.scala
+ *   LSH    src/main/scala/mclab/lsh/LSH.scala
+ *   Hasher src/main/scala/mclab/lsh/Hasher.scala
+ *   Part   src/main/scala/mclab/utils/Partitioner.scala
+ *   RDT    src/main/java/mclab/mapdb/RandomDrawTreeMap.java
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on
+ * success or a negative DPF_E* code, and dpf_last_error() returns the message
+ * of the last failure on that handle (or of the last failed dpf_create when
+ * called with NULL).  No exception crosses the boundary.  A handle serves one
+ * call at a time (the reference keeps its batch result in one shared field,
+ * Dense:324); distinct handles are independent.  "host" pointers are ordinary
+ * process memory, "device" pointers are HIP device memory on the handle's
+ * device.  All matrices are row-major and dense.
+ */
+#ifndef DPF_H
+#define DPF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DPF_OK          0
+#define DPF_EINVAL     -1   /* bad argument / unsupported configuration          */
+#define DPF_ENOTFIT    -2   /* query before fit: the reference prints "need to fit
+                               the data first" and returns empty sets, Dense:422-424 */
+#define DPF_ENOFAMILY  -3   /* hash family / partitioner not set                 */
+#define DPF_EHIP       -4   /* a HIP runtime call failed                         */
+#define DPF_ENOMEM     -5
+#define DPF_ECAPACITY  -6   /* index larger than the 32-bit arena limits (RDT:1330-1363) */
+
+enum { DPF_FAMILY_ANGLE = 0, DPF_FAMILY_PSTABLE = 1 };              /* mclab.lsh.name        */
+enum { DPF_INDEX_ORIGINAL = 0, DPF_INDEX_SAMPLING = 1,
+       DPF_INDEX_CONTINUE_BITS = 2, DPF_INDEX_ANGLE_NEW = 3 };      /* mclab.lsh.typeOfIndex */
+enum { DPF_SELF_COMPAT = 0, DPF_SELF_ALWAYS = 1, DPF_SELF_NEVER = 2 };
+enum { DPF_METRIC_DOT = 0, DPF_METRIC_L2 = 1 };
+enum { DPF_F32 = 0, DPF_F64 = 1 };
+
+/* The subset of the reference's Typesafe-Config keys the path consumes
+ * (TestSettings.scala:8-45; read at LSH:19-33, Dense:39-58). */
+typedef struct dpf_config {
+    int32_t family;           /* mclab.lsh.name                                   */
+    int32_t dim;              /* mclab.lsh.vectorDim                              */
+    int32_t num_functions;    /* size F of the function pool (mclab.lsh.familySize
+                                 when chains are pulled from the family)          */
+    int32_t num_tables;       /* L = tableNum * permutationNum (Dense:107)        */
+    int32_t chain_length;     /* mclab.lshTable.chainLength                       */
+    int32_t partition_bits;   /* mclab.lsh.partitionBits                          */
+    int32_t bucket_bits;      /* mclab.lshTable.bucketBits                        */
+    int32_t dir_node_size;    /* mclab.lshTable.dirNodeSize                       */
+    int32_t bucket_overflow;  /* mclab.lshTable.bufferOverflow                    */
+    int32_t type_of_index;    /* mclab.lsh.typeOfIndex                            */
+    int32_t exclude_self;     /* DPF_SELF_COMPAT reproduces RDT:982 exactly        */
+    int32_t metric;           /* rerank order: DPF_METRIC_DOT = Dense:490          */
+    int32_t top_k;            /* mclab.lsh.topK                                   */
+    int32_t dtype;            /* DPF_F32 / DPF_F64: element type of base and query
+                                 vectors at this boundary and in HBM              */
+    int32_t device;           /* HIP device ordinal                               */
+    int32_t reserved;
+    int64_t row_begin;        /* rerank shard: this handle scores only candidates  */
+    int64_t row_end;          /* with row_begin <= id < row_end; row_end < 0 = all */
+} dpf_config;
+
+typedef struct dpf_stats {
+    int64_t num_vectors;         /* ids fitted so far                              */
+    int64_t num_dnodes;          /* directory nodes in the snapshot                */
+    int64_t num_leaves;          /* buckets (k-node chains) in the snapshot        */
+    int64_t max_leaf;            /* longest bucket                                 */
+    int64_t misflag_events;      /* splits that hit the RDT:1733-1734 tag quirk    */
+    int64_t short_hash_events;   /* (query, table) pairs with 0 <= hash < 8, where
+                                    RDT:753 throws; such pairs return nothing      */
+    int64_t last_raw_candidates; /* last batch: ids visited before set union       */
+    int64_t last_unique_candidates; /* last batch: sum of per-query set sizes      */
+    double  last_ms_hash, last_ms_probe, last_ms_dedupe, last_ms_rerank;
+    int64_t snapshot_bytes;      /* HBM bytes of the forest snapshot               */
+    int64_t base_bytes;          /* HBM bytes of the resident base rows            */
+} dpf_stats;
+
+typedef struct dpf_index dpf_index;
+
+/* new LSH(conf) + DensevectorRDFInit.initializeRDFHashMap(conf)  (LSH:17-53, Dense:50-118). */
+int dpf_create(const dpf_config *cfg, dpf_index **out);
+/* DensevectorRDFInit.clearAndClose()  (Dense:453-458). */
+void dpf_destroy(dpf_index *ix);
+const char *dpf_last_error(const dpf_index *ix);
+
+/* The hash chains LSH.initHashChains builds (LSH:29-82): a pool fns[F][dim],
+ * b[F] and w[F] for pStable (NULL for angle), and chain_fn[L][chain_length]
+ * naming the pool function at each chain position (position 0 = top bit for
+ * angle, AngleHashFamily.scala:187-195).  Copied.  Host pointers. */
+int dpf_set_hash_family(dpf_index *ix, const double *fns, const double *b, const int32_t *w,
+                        const int32_t *chain_fn);
+/* One LocalitySensitivePartitioner per table (Dense:77, Part:27-64):
+ * part_fns[L][partition_bits][32]; part_b / part_w [L][partition_bits] for pStable. */
+int dpf_set_partitioner(dpf_index *ix, const double *part_fns, const double *part_b,
+                        const int32_t *part_w);
+/* The bit permutation of typeOfIndex = sampling (Sampling.scala:6-11), 32 entries. */
+int dpf_set_sampling_index(dpf_index *ix, const int32_t *sampling_index);
+
+/* DensevectorRDFInit.newFastFit / newMultiThreadFit (Dense:127-206) after the
+ * text has been parsed: appends n rows X[n][dim] (host, element type cfg.dtype);
+ * their ids continue the running counter (Dense:181,190).  Hashes are computed
+ * on the device; the forest snapshot is rebuilt and uploaded. */
+int dpf_fit(dpf_index *ix, const void *X, int64_t n);
+
+/* LocalitySensitiveHasher.hash for every table (Hasher:44-54 -> LSH:135-166)
+ * and LocalitySensitivePartitioner.getPartition of each hash (Part:40-59):
+ * hashes[nq][L], parts[nq][L] (parts may be NULL).  Host pointers. */
+int dpf_hash_batch(dpf_index *ix, const void *Q, int64_t nq, int32_t *hashes, int32_t *parts);
+
+/* DensevectorRDFInit.NewMultiThreadQueryBatch(queryArray, denseVectorArray, steps, _)
+ * (Dense:335-360): per query the Set of similar ids as a sorted unique list,
+ * restricted to [row_begin, row_end).  cand_offsets[nq+1] is caller memory;
+ * *cand_ids is allocated by the library, release with dpf_free.  Host pointers. */
+int dpf_query_batch(dpf_index *ix, const int32_t *qids, const void *Q, int64_t nq, int32_t steps,
+                    int64_t *cand_offsets, int32_t **cand_ids);
+void dpf_free(void *p);
+
+/* The query + rerank of DensevectorRDFInit.topKAndPrecisionScore (Dense:472-507)
+ * without the ground-truth scoring: ids[nq][k] (-1 padded) and scores[nq][k]
+ * (NaN padded), best first.  Host pointers. */
+int dpf_query_topk(dpf_index *ix, const int32_t *qids, const void *Q, int64_t nq, int32_t steps,
+                   int32_t k, int32_t *ids, double *scores);
+
+/* Same, every buffer already in HBM, enqueued on `stream` (a hipStream_t, NULL =
+ * the default stream); returns without synchronising. */
+int dpf_query_topk_device(dpf_index *ix, const int32_t *d_qids, const void *d_Q, int64_t nq,
+                          int32_t steps, int32_t k, int32_t *d_ids, double *d_scores, void *stream);
+
+/* Dense:477-505 alone: rerank caller-supplied candidate lists (host pointers). */
+int dpf_rerank(dpf_index *ix, const void *Q, int64_t nq, const int64_t *cand_offsets,
+               const int32_t *cand_ids, int32_t k, int32_t *ids, double *scores);
+
+/* Merge `parts` partial top-k lists per query (row-sharded handles on several
+ * devices, gathered by the caller): in_ids/in_scores [parts][nq][k] device
+ * memory -> d_ids/d_scores [nq][k].  No counterpart in the reference, which is
+ * a single process. */
+int dpf_merge_topk_device(dpf_index *ix, const int32_t *in_ids, const double *in_scores,
+                          int32_t parts, int64_t nq, int32_t k, int32_t *d_ids, double *d_scores,
+                          void *stream);
+
+/* RandomDrawTreeMap.allSubIndexObjectsNumberDistribution via
+ * DensevectorRDFInit.getDtAndHtNumDistribution (Dense:515-530):
+ * out[2^partition_bits] = mean number of ids per sub-index over the tables. */
+int dpf_subindex_distribution(dpf_index *ix, double *out);
+
+int dpf_get_stats(dpf_index *ix, dpf_stats *out);
+
+/* Device time of the dominant (rerank) kernel in the last *_topk* call, measured
+ * with HIP events on the stream the kernel ran on; and the bytes that launch
+ * had to move by definition (candidate rows + ids + queries + results). */
+int dpf_last_rerank_profile(dpf_index *ix, double *ms, int64_t *algorithmic_bytes);
+/* enable (1) / disable (0) the per-stage HIP-event timing (adds stream syncs) */
+int dpf_set_profiling(dpf_index *ix, int32_t on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,253 @@
+"""ctypes binding of the C ABI declared in include/dpf.h (libdpf.so).
+
+There is no CPU path: importing works anywhere, but creating an index needs a
+HIP device, and a missing libdpf.so raises at first use.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdpf.so")
+
+FAMILY = {"angle": 0, "pStable": 1}
+TYPE_OF_INDEX = {"original": 0, "sampling": 1, "continueBitsCount": 2, "angleNewMethod": 3}
+SELF = {"compat": 0, "always": 1, "never": 2}
+METRIC = {"dot": 0, "l2": 1}
+DTYPE = {np.dtype(np.float32): 0, np.dtype(np.float64): 1}
+
+DPF_OK, DPF_EINVAL, DPF_ENOTFIT, DPF_ENOFAMILY, DPF_EHIP, DPF_ENOMEM, DPF_ECAPACITY = 0, -1, -2, -3, -4, -5, -6
+
+
+class DpfConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "family", "dim", "num_functions", "num_tables", "chain_length", "partition_bits",
+        "bucket_bits", "dir_node_size", "bucket_overflow", "type_of_index", "exclude_self",
+        "metric", "top_k", "dtype", "device", "reserved")] + [("row_begin", C.c_int64), ("row_end", C.c_int64)]
+
+
+class DpfStats(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in (
+        "num_vectors", "num_dnodes", "num_leaves", "max_leaf", "misflag_events", "short_hash_events",
+        "last_raw_candidates", "last_unique_candidates")] + [
+        (n, C.c_double) for n in ("last_ms_hash", "last_ms_probe", "last_ms_dedupe", "last_ms_rerank")] + [
+        ("snapshot_bytes", C.c_int64), ("base_bytes", C.c_int64)]
+
+
+EXPORTS = (
+    "dpf_create", "dpf_destroy", "dpf_last_error", "dpf_set_hash_family", "dpf_set_partitioner",
+    "dpf_set_sampling_index", "dpf_fit", "dpf_hash_batch", "dpf_query_batch", "dpf_free",
+    "dpf_query_topk", "dpf_query_topk_device", "dpf_rerank", "dpf_merge_topk_device",
+    "dpf_subindex_distribution", "dpf_get_stats", "dpf_last_rerank_profile", "dpf_set_profiling",
+)
+
+_lib = None
+
+
+class DpfError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("dpf error %d: %s" % (code, msg))
+        self.code = code
+
+
+def lib():
+    """Loads libdpf.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s is missing: build it with `make -C similaritysearchbyrdf_amd/csrc` "
+                          "(or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, ip, dp, i64p = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_int64)
+    L.dpf_create.restype = C.c_int
+    L.dpf_create.argtypes = [C.POINTER(DpfConfig), C.POINTER(vp)]
+    L.dpf_destroy.restype = None
+    L.dpf_destroy.argtypes = [vp]
+    L.dpf_last_error.restype = C.c_char_p
+    L.dpf_last_error.argtypes = [vp]
+    L.dpf_set_hash_family.restype = C.c_int
+    L.dpf_set_hash_family.argtypes = [vp, dp, dp, ip, ip]
+    L.dpf_set_partitioner.restype = C.c_int
+    L.dpf_set_partitioner.argtypes = [vp, dp, dp, ip]
+    L.dpf_set_sampling_index.restype = C.c_int
+    L.dpf_set_sampling_index.argtypes = [vp, ip]
+    L.dpf_fit.restype = C.c_int
+    L.dpf_fit.argtypes = [vp, vp, C.c_int64]
+    L.dpf_hash_batch.restype = C.c_int
+    L.dpf_hash_batch.argtypes = [vp, vp, C.c_int64, ip, ip]
+    L.dpf_query_batch.restype = C.c_int
+    L.dpf_query_batch.argtypes = [vp, ip, vp, C.c_int64, C.c_int32, i64p, C.POINTER(ip)]
+    L.dpf_free.restype = None
+    L.dpf_free.argtypes = [vp]
+    L.dpf_query_topk.restype = C.c_int
+    L.dpf_query_topk.argtypes = [vp, ip, vp, C.c_int64, C.c_int32, C.c_int32, ip, dp]
+    L.dpf_query_topk_device.restype = C.c_int
+    L.dpf_query_topk_device.argtypes = [vp, vp, vp, C.c_int64, C.c_int32, C.c_int32, vp, vp, vp]
+    L.dpf_rerank.restype = C.c_int
+    L.dpf_rerank.argtypes = [vp, vp, C.c_int64, i64p, ip, C.c_int32, ip, dp]
+    L.dpf_merge_topk_device.restype = C.c_int
+    L.dpf_merge_topk_device.argtypes = [vp, vp, vp, C.c_int32, C.c_int64, C.c_int32, vp, vp, vp]
+    L.dpf_subindex_distribution.restype = C.c_int
+    L.dpf_subindex_distribution.argtypes = [vp, dp]
+    L.dpf_get_stats.restype = C.c_int
+    L.dpf_get_stats.argtypes = [vp, C.POINTER(DpfStats)]
+    L.dpf_last_rerank_profile.restype = C.c_int
+    L.dpf_last_rerank_profile.argtypes = [vp, dp, i64p]
+    L.dpf_set_profiling.restype = C.c_int
+    L.dpf_set_profiling.argtypes = [vp, C.c_int32]
+    _lib = L
+    return L
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def _f64(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i32(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.int32)
+
+
+class DpfIndex:
+    """One forest + base shard on one GPU, driven through the C ABI.
+
+    params: dict with fns [F,d], chain_fn [L,m], optional b/w [F], part_fns
+    [L,pb,32], part_b/part_w [L,pb], family, partition_bits, bucket_bits,
+    dir_node_size, bucket_overflow, type_of_index, exclude_self,
+    sampling_index; plus metric, top_k, dtype, device, row_begin, row_end.
+    """
+
+    def __init__(self, params, metric="dot", top_k=10, dtype=np.float32, device=0,
+                 row_begin=0, row_end=-1):
+        self.L_ = lib()
+        p = params
+        fns = _f64(p["fns"])
+        chain_fn = _i32(p["chain_fn"])
+        F, d = fns.shape
+        Lt, m = chain_fn.shape
+        pb = int(p.get("partition_bits", 3))
+        self.np_dtype = np.dtype(dtype)
+        self.cfg = DpfConfig(
+            family=FAMILY[p.get("family", "angle")], dim=d, num_functions=F, num_tables=Lt, chain_length=m,
+            partition_bits=pb, bucket_bits=int(p.get("bucket_bits", 28)),
+            dir_node_size=int(p.get("dir_node_size", 32)), bucket_overflow=int(p.get("bucket_overflow", 500)),
+            type_of_index=TYPE_OF_INDEX[p.get("type_of_index", "original")],
+            exclude_self=SELF[p.get("exclude_self", "compat")], metric=METRIC[metric], top_k=top_k,
+            dtype=DTYPE[self.np_dtype], device=device, reserved=0, row_begin=row_begin, row_end=row_end)
+        self.dim, self.L, self.pb, self.top_k = d, Lt, pb, top_k
+        self.h = C.c_void_p()
+        rc = self.L_.dpf_create(C.byref(self.cfg), C.byref(self.h))
+        if rc != 0:
+            raise DpfError(rc, self.L_.dpf_last_error(None).decode())
+        self._check(self.L_.dpf_set_hash_family(self.h, _dp(fns), _dp(_f64(p.get("b"))), _ip(_i32(p.get("w"))),
+                                                _ip(chain_fn)))
+        if pb > 0:
+            part_fns = _f64(p["part_fns"])
+            assert part_fns.shape == (Lt, pb, 32), part_fns.shape
+            self._check(self.L_.dpf_set_partitioner(self.h, _dp(part_fns), _dp(_f64(p.get("part_b"))),
+                                                    _ip(_i32(p.get("part_w")))))
+        if p.get("sampling_index") is not None:
+            self._check(self.L_.dpf_set_sampling_index(self.h, _ip(_i32(p["sampling_index"]))))
+
+    def _check(self, rc):
+        if rc != 0:
+            raise DpfError(rc, self.L_.dpf_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.L_.dpf_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _rows(self, X):
+        X = np.ascontiguousarray(X, dtype=self.np_dtype)
+        assert X.ndim == 2 and X.shape[1] == self.dim, X.shape
+        return X
+
+    def fit(self, X):
+        X = self._rows(X)
+        self._check(self.L_.dpf_fit(self.h, X.ctypes.data, X.shape[0]))
+
+    def hash_batch(self, Q):
+        Q = self._rows(Q)
+        nq = Q.shape[0]
+        h = np.empty((nq, self.L), dtype=np.int32)
+        p = np.empty((nq, self.L), dtype=np.int32)
+        self._check(self.L_.dpf_hash_batch(self.h, Q.ctypes.data, nq, _ip(h), _ip(p)))
+        return h, p
+
+    def query_batch(self, qids, Q, steps=0):
+        """NewMultiThreadQueryBatch -> (offsets [nq+1] int64, ids int32)."""
+        Q = self._rows(Q)
+        nq = Q.shape[0]
+        qids = _i32(qids)
+        offsets = np.zeros(nq + 1, dtype=np.int64)
+        pids = C.POINTER(C.c_int32)()
+        self._check(self.L_.dpf_query_batch(self.h, _ip(qids), Q.ctypes.data, nq, steps,
+                                            offsets.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(pids)))
+        total = int(offsets[nq])
+        ids = np.ctypeslib.as_array(pids, shape=(max(total, 1),))[:total].copy()
+        self.L_.dpf_free(pids)
+        return offsets, ids
+
+    def query_topk(self, qids, Q, steps=0, k=None):
+        Q = self._rows(Q)
+        nq = Q.shape[0]
+        k = k or self.top_k
+        qids = _i32(qids)
+        ids = np.empty((nq, k), dtype=np.int32)
+        sc = np.empty((nq, k), dtype=np.float64)
+        self._check(self.L_.dpf_query_topk(self.h, _ip(qids), Q.ctypes.data, nq, steps, k, _ip(ids), _dp(sc)))
+        return ids, sc
+
+    def query_topk_device(self, d_qids, d_Q, nq, steps, k, d_ids, d_scores, stream=None):
+        """All arguments are device addresses (ints); asynchronous on `stream`."""
+        self._check(self.L_.dpf_query_topk_device(self.h, d_qids, d_Q, nq, steps, k, d_ids, d_scores, stream))
+
+    def merge_topk_device(self, in_ids, in_scores, parts, nq, k, d_ids, d_scores, stream=None):
+        self._check(self.L_.dpf_merge_topk_device(self.h, in_ids, in_scores, parts, nq, k, d_ids, d_scores, stream))
+
+    def rerank(self, Q, offsets, cand, k=None):
+        Q = self._rows(Q)
+        nq = Q.shape[0]
+        k = k or self.top_k
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        cand = _i32(cand)
+        ids = np.empty((nq, k), dtype=np.int32)
+        sc = np.empty((nq, k), dtype=np.float64)
+        self._check(self.L_.dpf_rerank(self.h, Q.ctypes.data, nq, offsets.ctypes.data_as(C.POINTER(C.c_int64)),
+                                       _ip(cand), k, _ip(ids), _dp(sc)))
+        return ids, sc
+
+    def subindex_distribution(self):
+        out = np.zeros(1 << self.pb, dtype=np.float64)
+        self._check(self.L_.dpf_subindex_distribution(self.h, _dp(out)))
+        return out
+
+    def set_profiling(self, on):
+        self._check(self.L_.dpf_set_profiling(self.h, 1 if on else 0))
+
+    def stats(self):
+        st = DpfStats()
+        self._check(self.L_.dpf_get_stats(self.h, C.byref(st)))
+        return {n: getattr(st, n) for n, _ in DpfStats._fields_}
+
+    def last_rerank_profile(self):
+        ms = C.c_double()
+        by = C.c_int64()
+        self._check(self.L_.dpf_last_rerank_profile(self.h, C.byref(ms), C.byref(by)))
+        return ms.value, by.value

@@ -1,0 +1,691 @@
+// C ABI of the DPF batch-query engine (see include/dpf.h for the contract and
+// for the reference interfaces each entry point replaces).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/dpf.h"
+#include "dpf_device.hpp"
+#include "dpf_forest.hpp"
+
+using namespace dpf;
+
+namespace {
+
+std::string g_create_error;
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+        size_t want = bytes + bytes / 4 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { e = hipMalloc(&p, bytes); want = bytes; }
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <typename T> T *as() const { return (T *)p; }
+};
+
+}  // namespace
+
+struct dpf_index {
+    dpf_config cfg{};
+    ForestGeometry geo{};
+    std::string err;
+    int64_t row_begin = 0, row_end = 0;     // resolved shard
+    size_t elem = 4;
+    int64_t dpad = 0;                       // padded row length in elements
+    bool have_family = false, have_part = false;
+
+    std::vector<double> fns, b, part_fns, part_b;
+    std::vector<int32_t> w, chain_fn, part_w;
+    DevBuf d_fnsT, d_b, d_w, d_chain, d_part_fns, d_part_b, d_part_w;
+    HashParams hp{};
+
+    int64_t n = 0;
+    std::vector<int32_t> h_hashes, h_parts;  // [n][L]
+    DevBuf d_base;
+    int64_t base_rows = 0;                   // resident rows: ids row_begin .. row_begin+base_rows-1
+
+    DevBuf d_roots, d_dnodes, d_leaf_off, d_ids;
+    bool fitted = false;
+    dpf_stats st{};
+
+    // per-batch workspaces
+    DevBuf ws_qpad, ws_hashes, ws_parts, ws_raw, ws_bound, ws_off, ws_cnt, ws_arena, ws_misc;
+    DevBuf ws_hq, ws_hqids, ws_hids, ws_hscores;     // device copies for the host-pointer entry points
+    DevBuf ws_stage;                                  // fit staging
+    unsigned long long *d_short_hash = nullptr;
+    int64_t *pinned = nullptr;                        // host-pinned scratch (8 x int64)
+    hipEvent_t ev[6]{};
+    bool profiling = false;
+    int64_t last_nq = 0;
+    int32_t last_k = 0;
+    bool last_valid = false;
+};
+
+#define HIPCHECK(ix, call)                                                              \
+    do {                                                                                \
+        hipError_t e_ = (call);                                                         \
+        if (e_ != hipSuccess) {                                                         \
+            (ix)->err = std::string(#call) + ": " + hipGetErrorString(e_);              \
+            return DPF_EHIP;                                                            \
+        }                                                                               \
+    } while (0)
+
+static int fail(dpf_index *ix, int code, const std::string &msg)
+{
+    if (ix) ix->err = msg; else g_create_error = msg;
+    return code;
+}
+
+static void resolve_rows(dpf_index *ix)
+{
+    ix->row_begin = ix->cfg.row_begin < 0 ? 0 : ix->cfg.row_begin;
+    ix->row_end = ix->cfg.row_end < 0 ? INT64_MAX : ix->cfg.row_end;
+}
+
+extern "C" const char *dpf_last_error(const dpf_index *ix)
+{
+    return ix ? ix->err.c_str() : g_create_error.c_str();
+}
+
+extern "C" int dpf_create(const dpf_config *cfg, dpf_index **out)
+{
+    if (!cfg || !out) return fail(nullptr, DPF_EINVAL, "dpf_create: null argument");
+    *out = nullptr;
+    dpf_index *ix = new dpf_index();
+    ix->cfg = *cfg;
+    ForestGeometry &g = ix->geo;
+    g.num_tables = cfg->num_tables;
+    g.partition_bits = cfg->partition_bits;
+    g.bucket_bits = cfg->bucket_bits;
+    g.dir_node_size = cfg->dir_node_size;
+    g.chain_length = cfg->chain_length;
+    g.bucket_overflow = cfg->bucket_overflow;
+    std::string why;
+    if (cfg->family != DPF_FAMILY_ANGLE && cfg->family != DPF_FAMILY_PSTABLE) why = "family must be angle or pStable";
+    else if (cfg->dim < 1 || cfg->num_functions < 1 || cfg->num_tables < 1) why = "dim, num_functions and num_tables must be positive";
+    else if (cfg->chain_length < 1 || (cfg->family == DPF_FAMILY_ANGLE && cfg->chain_length > 32)) why = "chain_length must be in [1, 32] for the angle family";
+    else if (cfg->family == DPF_FAMILY_ANGLE && cfg->chain_length != 32)
+        // RandomDrawTreeMap.java:953 consumes the LOW bits of the hash while angle hashes are
+        // left-aligned (AngleHashFamily.scala:194): shorter chains put every id in slot 0.
+        why = "the angle family needs chain_length = 32";
+    else if (!g.derive()) why = "unsupported (bucket_bits, dir_node_size, chain_length, partition_bits, bucket_overflow) combination";
+    else if (cfg->dtype != DPF_F32 && cfg->dtype != DPF_F64) why = "dtype must be DPF_F32 or DPF_F64";
+    else if (cfg->top_k < 1 || cfg->top_k > 64) why = "top_k must be in [1, 64]";
+    else if (cfg->metric != DPF_METRIC_DOT && cfg->metric != DPF_METRIC_L2) why = "metric must be dot or l2";
+    else if (cfg->type_of_index < 0 || cfg->type_of_index > 3) why = "unknown type_of_index";
+    else if (cfg->exclude_self < 0 || cfg->exclude_self > 2) why = "unknown exclude_self mode";
+    if (!why.empty()) { delete ix; return fail(nullptr, DPF_EINVAL, "dpf_create: " + why); }
+    if (cfg->family == DPF_FAMILY_PSTABLE && cfg->chain_length > 1024) { delete ix; return fail(nullptr, DPF_EINVAL, "dpf_create: chain_length too large"); }
+    ix->elem = cfg->dtype == DPF_F32 ? 4 : 8;
+    const int64_t per16 = 16 / (int64_t)ix->elem;
+    ix->dpad = (cfg->dim + per16 - 1) / per16 * per16;
+    if (ix->dpad * (int64_t)ix->elem / 16 > rerank_max_chunks16()) { delete ix; return fail(nullptr, DPF_EINVAL, "dpf_create: dim too large for the rerank kernel"); }
+    resolve_rows(ix);
+
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev < 1) { delete ix; return fail(nullptr, DPF_EHIP, "dpf_create: no HIP device (this library has no CPU path)"); }
+    if (cfg->device < 0 || cfg->device >= ndev) { delete ix; return fail(nullptr, DPF_EINVAL, "dpf_create: bad device ordinal"); }
+    e = hipSetDevice(cfg->device);
+    if (e == hipSuccess && configure_kernels() != 0) e = hipErrorInvalidValue;
+    if (e == hipSuccess) e = hipMalloc((void **)&ix->d_short_hash, sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(ix->d_short_hash, 0, sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipHostMalloc((void **)&ix->pinned, 8 * sizeof(int64_t), hipHostMallocDefault);
+    for (int i = 0; i < 6 && e == hipSuccess; i++) e = hipEventCreate(&ix->ev[i]);
+    if (e != hipSuccess) {
+        std::string m = std::string("dpf_create: ") + hipGetErrorString(e);
+        delete ix;
+        return fail(nullptr, DPF_EHIP, m);
+    }
+    HashParams &hp = ix->hp;
+    hp.family = cfg->family; hp.dim = cfg->dim; hp.F = cfg->num_functions; hp.L = cfg->num_tables;
+    hp.m = cfg->chain_length; hp.pb = cfg->partition_bits; hp.type_of_index = cfg->type_of_index;
+    for (int i = 0; i < 32; i++) hp.sampling_index[i] = i;
+    // significantBits.angleDistance / newMethod (significantBits.scala:100-127): the label
+    // depends only on the popcount of the low 28 bits.
+    static const double metric[9] = {16.0, 25.0, 33.0, 39.0, 46.0, 52.0, 58.0, 66.0, 72.0};
+    for (int pc = 0; pc <= 28; pc++) {
+        double angle = std::acos((double)pc / (std::sqrt(28.0) * std::sqrt((double)pc)));
+        angle = angle * 360 / 2 / 3.141592653589793;
+        int idx = 0;
+        while (idx < 9 && angle > metric[idx]) idx++;
+        hp.angle_label_lut[pc] = idx;
+    }
+    if (hash_shmem_bytes(hp) > 150 * 1024) { dpf_destroy(ix); return fail(nullptr, DPF_EINVAL, "dpf_create: dim + num_functions too large for the hash kernel's LDS tile"); }
+    *out = ix;
+    return DPF_OK;
+}
+
+extern "C" void dpf_destroy(dpf_index *ix)
+{
+    if (!ix) return;
+    (void)hipSetDevice(ix->cfg.device);
+    DevBuf *bufs[] = {&ix->d_fnsT, &ix->d_b, &ix->d_w, &ix->d_chain, &ix->d_part_fns, &ix->d_part_b, &ix->d_part_w,
+                      &ix->d_base, &ix->d_roots, &ix->d_dnodes, &ix->d_leaf_off, &ix->d_ids, &ix->ws_qpad,
+                      &ix->ws_hashes, &ix->ws_parts, &ix->ws_raw, &ix->ws_bound, &ix->ws_off, &ix->ws_cnt,
+                      &ix->ws_arena, &ix->ws_misc, &ix->ws_hq, &ix->ws_hqids, &ix->ws_hids, &ix->ws_hscores, &ix->ws_stage};
+    for (DevBuf *b : bufs) b->release();
+    if (ix->d_short_hash) (void)hipFree(ix->d_short_hash);
+    if (ix->pinned) (void)hipHostFree(ix->pinned);
+    for (int i = 0; i < 6; i++) if (ix->ev[i]) (void)hipEventDestroy(ix->ev[i]);
+    delete ix;
+}
+
+template <typename T>
+static int upload(dpf_index *ix, DevBuf &buf, const std::vector<T> &v)
+{
+    size_t bytes = std::max<size_t>(v.size() * sizeof(T), 16);
+    HIPCHECK(ix, buf.ensure(bytes));
+    if (!v.empty()) HIPCHECK(ix, hipMemcpy(buf.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return DPF_OK;
+}
+
+extern "C" int dpf_set_hash_family(dpf_index *ix, const double *fns, const double *b, const int32_t *w,
+                                   const int32_t *chain_fn)
+{
+    if (!ix) return DPF_EINVAL;
+    if (!fns || !chain_fn) return fail(ix, DPF_EINVAL, "dpf_set_hash_family: null fns/chain_fn");
+    const dpf_config &c = ix->cfg;
+    if (c.family == DPF_FAMILY_PSTABLE && (!b || !w)) return fail(ix, DPF_EINVAL, "dpf_set_hash_family: pStable needs b and w");
+    if (ix->n > 0) return fail(ix, DPF_EINVAL, "dpf_set_hash_family: index already holds vectors");
+    const size_t F = c.num_functions, d = c.dim, L = c.num_tables, m = c.chain_length;
+    for (size_t i = 0; i < L * m; i++)
+        if (chain_fn[i] < 0 || chain_fn[i] >= (int32_t)F) return fail(ix, DPF_EINVAL, "dpf_set_hash_family: chain_fn entry outside the pool");
+    if (c.family == DPF_FAMILY_PSTABLE)
+        for (size_t f = 0; f < F; f++)
+            if (w[f] == 0) return fail(ix, DPF_EINVAL, "dpf_set_hash_family: w must be non-zero");
+    (void)hipSetDevice(c.device);
+    ix->fns.assign(fns, fns + F * d);
+    ix->chain_fn.assign(chain_fn, chain_fn + L * m);
+    std::vector<double> fnsT(F * d);
+    for (size_t f = 0; f < F; f++)
+        for (size_t i = 0; i < d; i++) fnsT[i * F + f] = fns[f * d + i];
+    int rc;
+    if ((rc = upload(ix, ix->d_fnsT, fnsT)) != DPF_OK) return rc;
+    if ((rc = upload(ix, ix->d_chain, ix->chain_fn)) != DPF_OK) return rc;
+    if (c.family == DPF_FAMILY_PSTABLE) {
+        ix->b.assign(b, b + F);
+        ix->w.assign(w, w + F);
+        if ((rc = upload(ix, ix->d_b, ix->b)) != DPF_OK) return rc;
+        if ((rc = upload(ix, ix->d_w, ix->w)) != DPF_OK) return rc;
+    }
+    ix->hp.fnsT = ix->d_fnsT.as<double>();
+    ix->hp.chain_fn = ix->d_chain.as<int32_t>();
+    ix->hp.b = ix->d_b.as<double>();
+    ix->hp.w = ix->d_w.as<int32_t>();
+    ix->have_family = true;
+    return DPF_OK;
+}
+
+extern "C" int dpf_set_partitioner(dpf_index *ix, const double *part_fns, const double *part_b, const int32_t *part_w)
+{
+    if (!ix) return DPF_EINVAL;
+    const dpf_config &c = ix->cfg;
+    const size_t L = c.num_tables, pb = c.partition_bits;
+    if (pb > 0 && !part_fns) return fail(ix, DPF_EINVAL, "dpf_set_partitioner: null part_fns");
+    if (pb > 0 && c.family == DPF_FAMILY_PSTABLE && (!part_b || !part_w)) return fail(ix, DPF_EINVAL, "dpf_set_partitioner: pStable needs part_b and part_w");
+    if (ix->n > 0) return fail(ix, DPF_EINVAL, "dpf_set_partitioner: index already holds vectors");
+    (void)hipSetDevice(c.device);
+    int rc;
+    ix->part_fns.assign(part_fns, part_fns + L * pb * 32);
+    if ((rc = upload(ix, ix->d_part_fns, ix->part_fns)) != DPF_OK) return rc;
+    if (c.family == DPF_FAMILY_PSTABLE && pb > 0) {
+        for (size_t i = 0; i < L * pb; i++)
+            if (part_w[i] == 0) return fail(ix, DPF_EINVAL, "dpf_set_partitioner: part_w must be non-zero");
+        ix->part_b.assign(part_b, part_b + L * pb);
+        ix->part_w.assign(part_w, part_w + L * pb);
+        if ((rc = upload(ix, ix->d_part_b, ix->part_b)) != DPF_OK) return rc;
+        if ((rc = upload(ix, ix->d_part_w, ix->part_w)) != DPF_OK) return rc;
+    }
+    ix->hp.part_fns = ix->d_part_fns.as<double>();
+    ix->hp.part_b = ix->d_part_b.as<double>();
+    ix->hp.part_w = ix->d_part_w.as<int32_t>();
+    ix->have_part = true;
+    return DPF_OK;
+}
+
+extern "C" int dpf_set_sampling_index(dpf_index *ix, const int32_t *si)
+{
+    if (!ix) return DPF_EINVAL;
+    if (!si) return fail(ix, DPF_EINVAL, "dpf_set_sampling_index: null");
+    bool seen[32] = {false};
+    for (int i = 0; i < 32; i++) {
+        if (si[i] < 0 || si[i] > 31 || seen[si[i]]) return fail(ix, DPF_EINVAL, "dpf_set_sampling_index: not a permutation of 0..31");
+        seen[si[i]] = true;
+    }
+    if (ix->n > 0) return fail(ix, DPF_EINVAL, "dpf_set_sampling_index: index already holds vectors");
+    for (int i = 0; i < 32; i++) ix->hp.sampling_index[i] = si[i];
+    return DPF_OK;
+}
+
+static int check_ready(dpf_index *ix, bool need_fit)
+{
+    if (!ix->have_family) return fail(ix, DPF_ENOFAMILY, "hash family not set (dpf_set_hash_family)");
+    if (ix->cfg.partition_bits > 0 && !ix->have_part) return fail(ix, DPF_ENOFAMILY, "partitioner not set (dpf_set_partitioner)");
+    if (need_fit && !ix->fitted) return fail(ix, DPF_ENOTFIT, "need to fit the data first");
+    return DPF_OK;
+}
+
+static int upload_snapshot(dpf_index *ix, const ForestSnapshot &s)
+{
+    int rc;
+    if ((rc = upload(ix, ix->d_roots, s.roots)) != DPF_OK) return rc;
+    if ((rc = upload(ix, ix->d_dnodes, s.dnodes)) != DPF_OK) return rc;
+    if ((rc = upload(ix, ix->d_leaf_off, s.leaf_off)) != DPF_OK) return rc;
+    if ((rc = upload(ix, ix->d_ids, s.ids)) != DPF_OK) return rc;
+    ix->st.num_dnodes = (int64_t)(s.dnodes.size() / ix->geo.dir_node_size) - 1;
+    ix->st.num_leaves = (int64_t)s.leaf_off.size() - 1;
+    ix->st.max_leaf = s.max_leaf;
+    ix->st.misflag_events = s.misflag_events;
+    ix->st.snapshot_bytes = (int64_t)(s.roots.size() * 4 + s.dnodes.size() * 4 + s.leaf_off.size() * 4 + s.ids.size() * 4);
+    return DPF_OK;
+}
+
+
+extern "C" int dpf_fit(dpf_index *ix, const void *X, int64_t n)
+{
+    if (!ix) return DPF_EINVAL;
+    int rc = check_ready(ix, false);
+    if (rc != DPF_OK) return rc;
+    if (n < 0 || (n > 0 && !X)) return fail(ix, DPF_EINVAL, "dpf_fit: bad arguments");
+    const dpf_config &c = ix->cfg;
+    const int L = c.num_tables, d = c.dim;
+    const int64_t first = ix->n, total = first + n;
+    if (total * L >= (int64_t)0x7fffffff) return fail(ix, DPF_ECAPACITY, "dpf_fit: more than 2^31 (id, table) pairs");
+    HIPCHECK(ix, hipSetDevice(c.device));
+
+    // grow the resident base shard
+    const int64_t res_begin = ix->row_begin;
+    const int64_t res_end = std::min<int64_t>(ix->row_end, total);
+    const int64_t new_rows = std::max<int64_t>(0, res_end - res_begin);
+    const size_t row_bytes = (size_t)ix->dpad * ix->elem;
+    if (new_rows > ix->base_rows) {
+        size_t need = std::max<size_t>((size_t)new_rows * row_bytes, 16);
+        if (need > ix->d_base.cap) {
+            DevBuf nb;
+            HIPCHECK(ix, nb.ensure(need));
+            if (ix->base_rows > 0) HIPCHECK(ix, hipMemcpy(nb.p, ix->d_base.p, (size_t)ix->base_rows * row_bytes, hipMemcpyDeviceToDevice));
+            ix->d_base.release();
+            ix->d_base = nb;
+        }
+    }
+    ix->h_hashes.resize((size_t)total * L);
+    ix->h_parts.resize((size_t)total * L);
+
+    const int64_t batch = 1 << 17;
+    HIPCHECK(ix, ix->ws_stage.ensure((size_t)std::min<int64_t>(batch, std::max<int64_t>(n, 1)) * d * ix->elem));
+    HIPCHECK(ix, ix->ws_hashes.ensure((size_t)std::min<int64_t>(batch, std::max<int64_t>(n, 1)) * L * 4));
+    HIPCHECK(ix, ix->ws_parts.ensure((size_t)std::min<int64_t>(batch, std::max<int64_t>(n, 1)) * L * 4));
+    for (int64_t s = 0; s < n; s += batch) {
+        const int64_t cnt = std::min(batch, n - s);
+        const char *src = (const char *)X + (size_t)s * d * ix->elem;
+        HIPCHECK(ix, hipMemcpy(ix->ws_stage.p, src, (size_t)cnt * d * ix->elem, hipMemcpyHostToDevice));
+        launch_hash(c.dtype, ix->ws_stage.p, d, cnt, ix->hp, ix->ws_hashes.as<int32_t>(), ix->ws_parts.as<int32_t>(), nullptr);
+        // rows of this batch that belong to the resident shard
+        const int64_t g0 = first + s, g1 = g0 + cnt;
+        const int64_t a = std::max(g0, res_begin), bnd = std::min(g1, res_end);
+        if (bnd > a) {
+            const char *rsrc = (const char *)ix->ws_stage.p + (size_t)(a - g0) * d * ix->elem;
+            char *rdst = (char *)ix->d_base.p + (size_t)(a - res_begin) * row_bytes;
+            launch_copy_rows(c.dtype, rsrc, bnd - a, d, rdst, ix->dpad, nullptr);
+        }
+        HIPCHECK(ix, hipMemcpy(ix->h_hashes.data() + (size_t)g0 * L, ix->ws_hashes.p, (size_t)cnt * L * 4, hipMemcpyDeviceToHost));
+        HIPCHECK(ix, hipMemcpy(ix->h_parts.data() + (size_t)g0 * L, ix->ws_parts.p, (size_t)cnt * L * 4, hipMemcpyDeviceToHost));
+    }
+    HIPCHECK(ix, hipDeviceSynchronize());
+    ix->base_rows = new_rows;
+    ix->n = total;
+    ix->st.num_vectors = total;
+    ix->st.base_bytes = (int64_t)((size_t)new_rows * row_bytes);
+
+    ForestSnapshot snap;
+    int hw = (int)std::thread::hardware_concurrency();
+    const char *env = getenv("OMP_NUM_THREADS");
+    int threads = env ? atoi(env) : std::min(hw > 0 ? hw : 8, 16);
+    if (threads < 1) threads = 1;
+    if (build_forest(ix->geo, ix->h_hashes.data(), ix->h_parts.data(), total, threads, snap) != 0)
+        return fail(ix, DPF_ECAPACITY, "dpf_fit: snapshot exceeds 32-bit arena indexing");
+    if ((rc = upload_snapshot(ix, snap)) != DPF_OK) return rc;
+    ix->fitted = total > 0;
+    ix->last_valid = false;
+    return DPF_OK;
+}
+
+extern "C" int dpf_subindex_distribution(dpf_index *ix, double *out)
+{
+    if (!ix || !out) return DPF_EINVAL;
+    const int P = ix->geo.num_parts, L = ix->cfg.num_tables;
+    std::vector<int64_t> cnt((size_t)P, 0);
+    for (int64_t i = 0; i < ix->n; i++)
+        for (int t = 0; t < L; t++) cnt[(size_t)ix->h_parts[(size_t)i * L + t]]++;
+    for (int p = 0; p < P; p++) out[p] = (double)cnt[(size_t)p] / (double)L;
+    return DPF_OK;
+}
+
+// pads the queries to whole 16-byte pieces when needed; returns the device rows to use
+static int pad_queries(dpf_index *ix, const void *d_Q, int64_t nq, hipStream_t stream, const void **out, int64_t *stride)
+{
+    if (ix->dpad == ix->cfg.dim) { *out = d_Q; *stride = ix->cfg.dim; return DPF_OK; }
+    HIPCHECK(ix, ix->ws_qpad.ensure((size_t)nq * ix->dpad * ix->elem));
+    launch_copy_rows(ix->cfg.dtype, d_Q, nq, ix->cfg.dim, ix->ws_qpad.p, ix->dpad, stream);
+    *out = ix->ws_qpad.p;
+    *stride = ix->dpad;
+    return DPF_OK;
+}
+
+static void fill_probe_params(dpf_index *ix, ProbeParams &pp, const int32_t *d_qids, int32_t steps)
+{
+    const ForestGeometry &g = ix->geo;
+    pp.roots = ix->d_roots.as<uint32_t>();
+    pp.dnodes = ix->d_dnodes.as<uint32_t>();
+    pp.leaf_off = ix->d_leaf_off.as<uint32_t>();
+    pp.ids = ix->d_ids.as<int32_t>();
+    pp.L = g.num_tables; pp.pb = g.partition_bits; pp.bucket_bits = g.bucket_bits; pp.seg = g.seg;
+    pp.nbits = g.nbits; pp.dns = g.dir_node_size; pp.max_level = g.max_level;
+    pp.steps = steps; pp.exclude_self = ix->cfg.exclude_self;
+    pp.qids = d_qids;
+    pp.hashes = ix->ws_hashes.as<int32_t>();
+    pp.parts = ix->ws_parts.as<int32_t>();
+    pp.row_begin = ix->row_begin;
+    pp.row_end = std::min<int64_t>(ix->row_end, ix->n);
+    if (pp.row_end < pp.row_begin) pp.row_end = pp.row_begin;
+    const int64_t range = pp.row_end - pp.row_begin;
+    const int64_t max_words = 32768;                 // 128 KiB bitmap = 2^20 ids per pass
+    int64_t words = (range + 31) / 32;
+    pp.chunk_words = (int32_t)std::max<int64_t>(1, std::min(words, max_words));
+    pp.raw = ix->ws_raw.as<unsigned long long>();
+    pp.bound = ix->ws_bound.as<int64_t>();
+    pp.short_hash_events = ix->d_short_hash;
+    pp.cand_off = ix->ws_off.as<int64_t>();
+    pp.cand = ix->ws_arena.as<int32_t>();
+    pp.cnt = ix->ws_cnt.as<int32_t>();
+}
+
+// hash -> count -> scan -> (sync: arena size) -> dedupe.  Leaves the per-query
+// sets in ws_arena at ws_off[q], sizes in ws_cnt.
+static int run_probe(dpf_index *ix, const int32_t *d_qids, const void *d_Qpad, int64_t q_stride, int64_t nq,
+                     int32_t steps, hipStream_t stream)
+{
+    const int L = ix->cfg.num_tables;
+    HIPCHECK(ix, ix->ws_hashes.ensure((size_t)nq * L * 4));
+    HIPCHECK(ix, ix->ws_parts.ensure((size_t)nq * L * 4));
+    HIPCHECK(ix, ix->ws_raw.ensure((size_t)nq * 8));
+    HIPCHECK(ix, ix->ws_bound.ensure((size_t)nq * 8));
+    HIPCHECK(ix, ix->ws_off.ensure((size_t)(nq + 1) * 8));
+    HIPCHECK(ix, ix->ws_cnt.ensure((size_t)nq * 4));
+    if (ix->profiling) HIPCHECK(ix, hipEventRecord(ix->ev[0], stream));
+    launch_hash(ix->cfg.dtype, d_Qpad, q_stride, nq, ix->hp, ix->ws_hashes.as<int32_t>(), ix->ws_parts.as<int32_t>(), stream);
+    if (ix->profiling) HIPCHECK(ix, hipEventRecord(ix->ev[1], stream));
+    ProbeParams pp;
+    fill_probe_params(ix, pp, d_qids, steps);
+    launch_probe(0, pp, nq, stream);
+    launch_scan_i64(pp.bound, nq, ix->ws_off.as<int64_t>(), stream);
+    HIPCHECK(ix, hipMemcpyAsync(ix->pinned, ix->ws_off.as<int64_t>() + nq, 8, hipMemcpyDeviceToHost, stream));
+    HIPCHECK(ix, hipStreamSynchronize(stream));
+    const int64_t total = ix->pinned[0];
+    HIPCHECK(ix, ix->ws_arena.ensure((size_t)std::max<int64_t>(total, 1) * 4));
+    fill_probe_params(ix, pp, d_qids, steps);
+    if (ix->profiling) HIPCHECK(ix, hipEventRecord(ix->ev[2], stream));
+    launch_probe(1, pp, nq, stream);
+    if (ix->profiling) HIPCHECK(ix, hipEventRecord(ix->ev[3], stream));
+    HIPCHECK(ix, hipGetLastError());
+    ix->last_nq = nq;
+    ix->last_valid = true;
+    return DPF_OK;
+}
+
+static void fill_rerank_params(dpf_index *ix, RerankParams &rp, const void *d_Qpad, int32_t k,
+                               const int64_t *off, const int32_t *cnt, const int32_t *cand,
+                               int32_t *d_ids, double *d_scores)
+{
+    rp.Q = d_Qpad;
+    rp.q_stride_bytes = ix->dpad * (int64_t)ix->elem;
+    rp.base = ix->d_base.p;
+    rp.base_stride_bytes = ix->dpad * (int64_t)ix->elem;
+    rp.chunks16 = (int32_t)(ix->dpad * (int64_t)ix->elem / 16);
+    rp.k = k;
+    rp.row_begin = ix->row_begin;
+    rp.row_end = ix->row_begin + ix->base_rows;
+    rp.cand_off = off; rp.cnt = cnt; rp.cand = cand;
+    rp.out_ids = d_ids; rp.out_scores = d_scores;
+}
+
+extern "C" int dpf_query_topk_device(dpf_index *ix, const int32_t *d_qids, const void *d_Q, int64_t nq,
+                                     int32_t steps, int32_t k, int32_t *d_ids, double *d_scores, void *stream_)
+{
+    if (!ix) return DPF_EINVAL;
+    int rc = check_ready(ix, true);
+    if (rc != DPF_OK) return rc;
+    if (nq < 0 || steps < 0 || k < 1 || k > 64 || (nq > 0 && (!d_Q || !d_ids || !d_scores)))
+        return fail(ix, DPF_EINVAL, "dpf_query_topk_device: bad arguments");
+    if (nq == 0) return DPF_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+    HIPCHECK(ix, hipSetDevice(ix->cfg.device));
+    const void *qpad; int64_t qstride;
+    // the rerank kernel reads whole 16-byte pieces, so it always gets padded rows
+    if ((rc = pad_queries(ix, d_Q, nq, stream, &qpad, &qstride)) != DPF_OK) return rc;
+    if ((rc = run_probe(ix, d_qids, qpad, qstride, nq, steps, stream)) != DPF_OK) return rc;
+    RerankParams rp;
+    fill_rerank_params(ix, rp, qpad, k, ix->ws_off.as<int64_t>(), ix->ws_cnt.as<int32_t>(), ix->ws_arena.as<int32_t>(), d_ids, d_scores);
+    HIPCHECK(ix, hipEventRecord(ix->ev[4], stream));
+    launch_rerank(ix->cfg.dtype, ix->cfg.metric, rp, nq, stream);
+    HIPCHECK(ix, hipEventRecord(ix->ev[5], stream));
+    HIPCHECK(ix, hipGetLastError());
+    ix->last_k = k;
+    return DPF_OK;
+}
+
+extern "C" int dpf_query_topk(dpf_index *ix, const int32_t *qids, const void *Q, int64_t nq, int32_t steps,
+                              int32_t k, int32_t *ids, double *scores)
+{
+    if (!ix) return DPF_EINVAL;
+    int rc = check_ready(ix, true);
+    if (rc != DPF_OK) return rc;
+    if (nq < 0 || (nq > 0 && (!Q || !ids || !scores)) || k < 1 || k > 64) return fail(ix, DPF_EINVAL, "dpf_query_topk: bad arguments");
+    if (nq == 0) return DPF_OK;
+    HIPCHECK(ix, hipSetDevice(ix->cfg.device));
+    const size_t qbytes = (size_t)nq * ix->cfg.dim * ix->elem;
+    HIPCHECK(ix, ix->ws_hq.ensure(qbytes));
+    HIPCHECK(ix, ix->ws_hids.ensure((size_t)nq * k * 4));
+    HIPCHECK(ix, ix->ws_hscores.ensure((size_t)nq * k * 8));
+    HIPCHECK(ix, hipMemcpy(ix->ws_hq.p, Q, qbytes, hipMemcpyHostToDevice));
+    const int32_t *dq = nullptr;
+    if (qids) {
+        HIPCHECK(ix, ix->ws_hqids.ensure((size_t)nq * 4));
+        HIPCHECK(ix, hipMemcpy(ix->ws_hqids.p, qids, (size_t)nq * 4, hipMemcpyHostToDevice));
+        dq = ix->ws_hqids.as<int32_t>();
+    }
+    rc = dpf_query_topk_device(ix, dq, ix->ws_hq.p, nq, steps, k, ix->ws_hids.as<int32_t>(), ix->ws_hscores.as<double>(), nullptr);
+    if (rc != DPF_OK) return rc;
+    HIPCHECK(ix, hipMemcpy(ids, ix->ws_hids.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost));
+    HIPCHECK(ix, hipMemcpy(scores, ix->ws_hscores.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost));
+    return DPF_OK;
+}
+
+extern "C" int dpf_hash_batch(dpf_index *ix, const void *Q, int64_t nq, int32_t *hashes, int32_t *parts)
+{
+    if (!ix) return DPF_EINVAL;
+    int rc = check_ready(ix, false);
+    if (rc != DPF_OK) return rc;
+    if (nq < 0 || (nq > 0 && (!Q || !hashes))) return fail(ix, DPF_EINVAL, "dpf_hash_batch: bad arguments");
+    if (nq == 0) return DPF_OK;
+    HIPCHECK(ix, hipSetDevice(ix->cfg.device));
+    const int L = ix->cfg.num_tables;
+    const size_t qbytes = (size_t)nq * ix->cfg.dim * ix->elem;
+    HIPCHECK(ix, ix->ws_hq.ensure(qbytes));
+    HIPCHECK(ix, ix->ws_hashes.ensure((size_t)nq * L * 4));
+    HIPCHECK(ix, ix->ws_parts.ensure((size_t)nq * L * 4));
+    HIPCHECK(ix, hipMemcpy(ix->ws_hq.p, Q, qbytes, hipMemcpyHostToDevice));
+    launch_hash(ix->cfg.dtype, ix->ws_hq.p, ix->cfg.dim, nq, ix->hp, ix->ws_hashes.as<int32_t>(), ix->ws_parts.as<int32_t>(), nullptr);
+    HIPCHECK(ix, hipGetLastError());
+    HIPCHECK(ix, hipMemcpy(hashes, ix->ws_hashes.p, (size_t)nq * L * 4, hipMemcpyDeviceToHost));
+    if (parts) HIPCHECK(ix, hipMemcpy(parts, ix->ws_parts.p, (size_t)nq * L * 4, hipMemcpyDeviceToHost));
+    ix->last_valid = false;
+    return DPF_OK;
+}
+
+extern "C" int dpf_query_batch(dpf_index *ix, const int32_t *qids, const void *Q, int64_t nq, int32_t steps,
+                               int64_t *cand_offsets, int32_t **cand_ids)
+{
+    if (!ix) return DPF_EINVAL;
+    if (cand_ids) *cand_ids = nullptr;
+    int rc = check_ready(ix, true);
+    if (rc == DPF_ENOTFIT && cand_offsets && nq >= 0) {
+        // Dense:422-424: an unfitted index yields empty sets
+        for (int64_t i = 0; i <= nq; i++) cand_offsets[i] = 0;
+        return rc;
+    }
+    if (rc != DPF_OK) return rc;
+    if (nq < 0 || steps < 0 || !cand_offsets || !cand_ids || (nq > 0 && !Q)) return fail(ix, DPF_EINVAL, "dpf_query_batch: bad arguments");
+    cand_offsets[0] = 0;
+    if (nq == 0) { *cand_ids = (int32_t *)malloc(4); return DPF_OK; }
+    HIPCHECK(ix, hipSetDevice(ix->cfg.device));
+    const size_t qbytes = (size_t)nq * ix->cfg.dim * ix->elem;
+    HIPCHECK(ix, ix->ws_hq.ensure(qbytes));
+    HIPCHECK(ix, hipMemcpy(ix->ws_hq.p, Q, qbytes, hipMemcpyHostToDevice));
+    const int32_t *dq = nullptr;
+    if (qids) {
+        HIPCHECK(ix, ix->ws_hqids.ensure((size_t)nq * 4));
+        HIPCHECK(ix, hipMemcpy(ix->ws_hqids.p, qids, (size_t)nq * 4, hipMemcpyHostToDevice));
+        dq = ix->ws_hqids.as<int32_t>();
+    }
+    if ((rc = run_probe(ix, dq, ix->ws_hq.p, ix->cfg.dim, nq, steps, nullptr)) != DPF_OK) return rc;
+    // compact the per-query sets into one CSR array
+    HIPCHECK(ix, ix->ws_misc.ensure((size_t)(nq + 1) * 8));
+    launch_scan_i32(ix->ws_cnt.as<int32_t>(), nq, ix->ws_misc.as<int64_t>(), nullptr);
+    HIPCHECK(ix, hipMemcpy(cand_offsets, ix->ws_misc.p, (size_t)(nq + 1) * 8, hipMemcpyDeviceToHost));
+    const int64_t total = cand_offsets[nq];
+    int32_t *host = (int32_t *)malloc((size_t)std::max<int64_t>(total, 1) * 4);
+    if (!host) return fail(ix, DPF_ENOMEM, "dpf_query_batch: out of host memory");
+    if (total > 0) {
+        DevBuf dst;
+        hipError_t e = dst.ensure((size_t)total * 4);
+        if (e != hipSuccess) { free(host); ix->err = hipGetErrorString(e); return DPF_EHIP; }
+        launch_compact(ix->ws_arena.as<int32_t>(), ix->ws_off.as<int64_t>(), ix->ws_cnt.as<int32_t>(), ix->ws_misc.as<int64_t>(), dst.as<int32_t>(), nq, nullptr);
+        e = hipMemcpy(host, dst.p, (size_t)total * 4, hipMemcpyDeviceToHost);
+        dst.release();
+        if (e != hipSuccess) { free(host); ix->err = hipGetErrorString(e); return DPF_EHIP; }
+    }
+    *cand_ids = host;
+    return DPF_OK;
+}
+
+extern "C" void dpf_free(void *p) { free(p); }
+
+extern "C" int dpf_rerank(dpf_index *ix, const void *Q, int64_t nq, const int64_t *cand_offsets,
+                          const int32_t *cand_ids, int32_t k, int32_t *ids, double *scores)
+{
+    if (!ix) return DPF_EINVAL;
+    int rc = check_ready(ix, true);
+    if (rc != DPF_OK) return rc;
+    if (nq < 0 || k < 1 || k > 64 || (nq > 0 && (!Q || !cand_offsets || !ids || !scores))) return fail(ix, DPF_EINVAL, "dpf_rerank: bad arguments");
+    if (nq == 0) return DPF_OK;
+    const int64_t total = cand_offsets[nq];
+    if (total < 0 || (total > 0 && !cand_ids)) return fail(ix, DPF_EINVAL, "dpf_rerank: bad candidate lists");
+    HIPCHECK(ix, hipSetDevice(ix->cfg.device));
+    const size_t qbytes = (size_t)nq * ix->cfg.dim * ix->elem;
+    HIPCHECK(ix, ix->ws_hq.ensure(qbytes));
+    HIPCHECK(ix, ix->ws_hids.ensure((size_t)nq * k * 4));
+    HIPCHECK(ix, ix->ws_hscores.ensure((size_t)nq * k * 8));
+    HIPCHECK(ix, ix->ws_off.ensure((size_t)(nq + 1) * 8));
+    HIPCHECK(ix, ix->ws_arena.ensure((size_t)std::max<int64_t>(total, 1) * 4));
+    HIPCHECK(ix, hipMemcpy(ix->ws_hq.p, Q, qbytes, hipMemcpyHostToDevice));
+    HIPCHECK(ix, hipMemcpy(ix->ws_off.p, cand_offsets, (size_t)(nq + 1) * 8, hipMemcpyHostToDevice));
+    if (total > 0) HIPCHECK(ix, hipMemcpy(ix->ws_arena.p, cand_ids, (size_t)total * 4, hipMemcpyHostToDevice));
+    const void *qpad; int64_t qstride;
+    if ((rc = pad_queries(ix, ix->ws_hq.p, nq, nullptr, &qpad, &qstride)) != DPF_OK) return rc;
+    RerankParams rp;
+    fill_rerank_params(ix, rp, qpad, k, ix->ws_off.as<int64_t>(), nullptr, ix->ws_arena.as<int32_t>(), ix->ws_hids.as<int32_t>(), ix->ws_hscores.as<double>());
+    launch_rerank(ix->cfg.dtype, ix->cfg.metric, rp, nq, nullptr);
+    HIPCHECK(ix, hipGetLastError());
+    HIPCHECK(ix, hipMemcpy(ids, ix->ws_hids.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost));
+    HIPCHECK(ix, hipMemcpy(scores, ix->ws_hscores.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost));
+    ix->last_valid = false;
+    return DPF_OK;
+}
+
+extern "C" int dpf_merge_topk_device(dpf_index *ix, const int32_t *in_ids, const double *in_scores, int32_t parts,
+                                     int64_t nq, int32_t k, int32_t *d_ids, double *d_scores, void *stream)
+{
+    if (!ix) return DPF_EINVAL;
+    if (parts < 1 || parts > 64 || k < 1 || nq < 0 || !in_ids || !in_scores || !d_ids || !d_scores)
+        return fail(ix, DPF_EINVAL, "dpf_merge_topk_device: bad arguments");
+    HIPCHECK(ix, hipSetDevice(ix->cfg.device));
+    launch_merge_topk(ix->cfg.metric, in_ids, in_scores, parts, nq, k, d_ids, d_scores, (hipStream_t)stream);
+    HIPCHECK(ix, hipGetLastError());
+    return DPF_OK;
+}
+
+extern "C" int dpf_set_profiling(dpf_index *ix, int32_t on)
+{
+    if (!ix) return DPF_EINVAL;
+    ix->profiling = on != 0;
+    return DPF_OK;
+}
+
+static int last_totals(dpf_index *ix, int64_t *raw_total, int64_t *uniq_total)
+{
+    *raw_total = 0; *uniq_total = 0;
+    if (!ix->last_valid || ix->last_nq <= 0) return DPF_OK;
+    std::vector<unsigned long long> raw((size_t)ix->last_nq);
+    std::vector<int32_t> cnt((size_t)ix->last_nq);
+    HIPCHECK(ix, hipMemcpy(raw.data(), ix->ws_raw.p, raw.size() * 8, hipMemcpyDeviceToHost));
+    HIPCHECK(ix, hipMemcpy(cnt.data(), ix->ws_cnt.p, cnt.size() * 4, hipMemcpyDeviceToHost));
+    for (auto v : raw) *raw_total += (int64_t)v;
+    for (auto v : cnt) *uniq_total += v;
+    return DPF_OK;
+}
+
+extern "C" int dpf_get_stats(dpf_index *ix, dpf_stats *out)
+{
+    if (!ix || !out) return DPF_EINVAL;
+    HIPCHECK(ix, hipSetDevice(ix->cfg.device));
+    HIPCHECK(ix, hipDeviceSynchronize());
+    unsigned long long sh = 0;
+    HIPCHECK(ix, hipMemcpy(&sh, ix->d_short_hash, 8, hipMemcpyDeviceToHost));
+    ix->st.short_hash_events = (int64_t)sh;
+    int rc = last_totals(ix, &ix->st.last_raw_candidates, &ix->st.last_unique_candidates);
+    if (rc != DPF_OK) return rc;
+    if (ix->profiling && ix->last_valid) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, ix->ev[0], ix->ev[1]) == hipSuccess) ix->st.last_ms_hash = ms;
+        if (hipEventElapsedTime(&ms, ix->ev[1], ix->ev[2]) == hipSuccess) ix->st.last_ms_probe = ms;
+        if (hipEventElapsedTime(&ms, ix->ev[2], ix->ev[3]) == hipSuccess) ix->st.last_ms_dedupe = ms;
+        if (ix->last_k > 0 && hipEventElapsedTime(&ms, ix->ev[4], ix->ev[5]) == hipSuccess) ix->st.last_ms_rerank = ms;
+    }
+    *out = ix->st;
+    return DPF_OK;
+}
+
+extern "C" int dpf_last_rerank_profile(dpf_index *ix, double *ms, int64_t *algorithmic_bytes)
+{
+    if (!ix) return DPF_EINVAL;
+    if (!ix->last_valid || ix->last_k <= 0) return fail(ix, DPF_EINVAL, "dpf_last_rerank_profile: no top-k batch has run");
+    HIPCHECK(ix, hipSetDevice(ix->cfg.device));
+    HIPCHECK(ix, hipEventSynchronize(ix->ev[5]));
+    float t = 0;
+    HIPCHECK(ix, hipEventElapsedTime(&t, ix->ev[4], ix->ev[5]));
+    int64_t raw = 0, uniq = 0;
+    int rc = last_totals(ix, &raw, &uniq);
+    if (rc != DPF_OK) return rc;
+    if (ms) *ms = t;
+    // candidate rows + candidate ids + query rows + (score, id) results
+    const int64_t row = (int64_t)ix->cfg.dim * (int64_t)ix->elem;
+    if (algorithmic_bytes) *algorithmic_bytes = uniq * (row + 4) + ix->last_nq * row + ix->last_nq * (int64_t)ix->last_k * 12;
+    return DPF_OK;
+}

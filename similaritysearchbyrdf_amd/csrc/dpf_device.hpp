@@ -1,0 +1,84 @@
+// Parameter blocks and launchers shared by the kernels and the C ABI.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+namespace dpf {
+
+static constexpr uint32_t NO_LEAF = 0xffffffffu;
+
+// Everything k_hash needs besides the vectors (all pointers device memory).
+struct HashParams {
+    int32_t family;          // 0 angle, 1 pStable
+    int32_t dim, F, L, m, pb;
+    int32_t type_of_index;
+    const double *fnsT;      // [dim][F]  transposed function pool
+    const double *b;         // [F]       pStable offsets
+    const int32_t *w;        // [F]       pStable widths
+    const int32_t *chain_fn; // [L][m]
+    const double *part_fns;  // [L][pb][32]
+    const double *part_b;    // [L][pb]
+    const int32_t *part_w;   // [L][pb]
+    int32_t sampling_index[32];
+    int32_t angle_label_lut[29];
+};
+
+struct ProbeParams {
+    // forest snapshot
+    const uint32_t *roots;    // [L][P][SEG]
+    const uint32_t *dnodes;   // [num_dnodes][DNS]
+    const uint32_t *leaf_off; // [num_leaves + 1]
+    const int32_t *ids;       // bucket contents
+    int32_t L, pb, bucket_bits, seg, nbits, dns, max_level;
+    int32_t steps, exclude_self;
+    // query batch
+    const int32_t *qids;      // [nq] or nullptr
+    const int32_t *hashes;    // [nq][L]
+    const int32_t *parts;     // [nq][L]
+    int64_t row_begin, row_end;
+    int32_t chunk_words;      // LDS bitmap words per pass (mode 1)
+    // mode 0 outputs
+    unsigned long long *raw;  // [nq] ids visited (duplicates included)
+    int64_t *bound;           // [nq] min(raw, rows in shard)
+    unsigned long long *short_hash_events;
+    // mode 1 inputs / outputs
+    const int64_t *cand_off;  // [nq + 1] exclusive scan of bound
+    int32_t *cand;            // candidate arena
+    int32_t *cnt;             // [nq] set sizes
+};
+
+struct RerankParams {
+    const void *Q;            // [nq] padded rows
+    int64_t q_stride_bytes;
+    const void *base;         // rows row_begin .. row_end-1, padded
+    int64_t base_stride_bytes;
+    int32_t chunks16;         // 16-byte pieces per padded row
+    int32_t k;
+    int64_t row_begin, row_end;
+    const int64_t *cand_off;  // [nq + 1]
+    const int32_t *cnt;       // [nq] or nullptr (then cand_off[q+1]-cand_off[q])
+    const int32_t *cand;
+    int32_t *out_ids;         // [nq][k]
+    double *out_scores;       // [nq][k]
+};
+
+void launch_hash(int dtype, const void *X, int64_t x_stride, int64_t n, const HashParams &p,
+                 int32_t *hashes, int32_t *parts, hipStream_t stream);
+size_t hash_shmem_bytes(const HashParams &p);
+void launch_probe(int mode, const ProbeParams &p, int64_t nq, hipStream_t stream);
+void launch_scan_i64(const int64_t *in, int64_t n, int64_t *off, hipStream_t stream);
+void launch_scan_i32(const int32_t *in, int64_t n, int64_t *off, hipStream_t stream);
+void launch_compact(const int32_t *src, const int64_t *src_off, const int32_t *cnt,
+                    const int64_t *dst_off, int32_t *dst, int64_t nq, hipStream_t stream);
+void launch_rerank(int dtype, int metric, const RerankParams &p, int64_t nq, hipStream_t stream);
+int rerank_max_chunks16();
+void launch_merge_topk(int metric, const int32_t *in_ids, const double *in_scores, int parts,
+                       int64_t nq, int k, int32_t *out_ids, double *out_scores, hipStream_t stream);
+void launch_copy_rows(int dtype, const void *src, int64_t n, int dim, void *dst, int64_t dst_stride,
+                      hipStream_t stream);
+int configure_kernels();
+
+}  // namespace dpf

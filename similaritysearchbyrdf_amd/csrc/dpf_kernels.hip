@@ -1,0 +1,757 @@
+// gfx950 kernels of the Dynamic Partition Forest batch-query path.
+//
+//   k_hash        LSH projection + hash assembly + sub-index id      (fp64 VALU, exact order)
+//   k_probe       multi-probe / multi-step trie walk; counts or sets candidate bits
+//   k_scan        exclusive scan of per-query candidate bounds
+//   k_rerank      candidate-row gather + distance + per-query top-k  (HBM-bound)
+//   k_merge_topk  merge of partial top-k lists
+//   k_compact     gathers the per-query sets into one CSR array
+//
+// Reference citations (paths relative to the reference checkout):
+//   Angle   src/main/scala/mclab/lsh/hashFamilies/AngleHashFamily.scala
+//   PStable src/main/scala/mclab/lsh/hashFamilies/PStableHashFamily.scala
+//   Sim     src/main/scala/mclab/lsh/vector/SimilarityCalculator.scala
+//   Part    src/main/scala/mclab/utils/Partitioner.scala
+//   RDT     src/main/java/mclab/mapdb/RandomDrawTreeMap.java
+//   Dense   src/main/scala/mclab/deploy/DensevectorRDFInit.scala
+//
+// The whole file is compiled with -ffp-contract=off: the hash bits must match a
+// JVM that never fuses a multiply with an add (Sim:46-47).  Where a fused
+// multiply-add is wanted (rerank) it is written as fma().
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+
+#include "dpf_device.hpp"
+
+#pragma clang fp contract(off)
+
+namespace dpf {
+
+// ---------------------------------------------------------------------------
+// hash post-transforms (LSH.scala:152-162)
+// ---------------------------------------------------------------------------
+
+// significantBits.continueBitsCount(key, Array(6,4,2,1)) -- significantBits.scala:11-67
+__device__ inline int32_t continue_bits_count(int32_t key)
+{
+    const uint32_t k = (uint32_t)key;
+    int a0 = 0, a1 = 0, a2 = 0, a3 = 0, count = 0;
+    for (int i = 0; i < 28; i++) {
+        bool one = (k >> i) & 1u;
+        if (one) count++;
+        if (!one || i == 27) {
+            if (count >= 6) { a0++; a1++; a2++; a3++; }
+            else if (count >= 4) { a1++; a2++; a3++; }
+            else if (count >= 2) { a2++; a3++; }
+            else if (count >= 1) { a3++; }
+            count = 0;
+        }
+    }
+    uint32_t tmp = ((uint32_t)a3 << 21) + ((uint32_t)a2 << 14) + ((uint32_t)a1 << 7) + (uint32_t)a0;
+    tmp += (k >> 28) << 28;
+    return (int32_t)tmp;
+}
+
+// Sampling.samplingOneKey -- Sampling.scala:32-39
+__device__ inline int32_t sampling_one_key(int32_t key, const int32_t *si)
+{
+    uint32_t tmp = 0;
+    for (int j = 0; j < 32; j++) tmp += (((uint32_t)key >> (si[j] & 31)) & 1u) << (31 - j);
+    return (int32_t)tmp;
+}
+
+// significantBits.newMethod -- significantBits.scala:113-127.  The angle it
+// thresholds depends only on the popcount of the low 28 bits, so the label is a
+// 29-entry table (computed on the host with the same formula).
+__device__ inline int32_t angle_new_method(int32_t key, const int32_t *label_lut)
+{
+    const uint32_t k = (uint32_t)key, mask = 0x7f;
+    uint32_t label = (uint32_t)label_lut[__popc(k & 0x0fffffffu)];
+    return (int32_t)((k & mask) + (((k >> 7) & mask) << 7) + (label << 14) + (((k >> 21) & mask) << 21) +
+                     (((k >> 28) & mask) << 28));
+}
+
+__device__ inline int32_t apply_type_of_index(int32_t h, const HashParams &p)
+{
+    switch (p.type_of_index) {
+    case 1: return sampling_one_key(h, p.sampling_index);
+    case 2: return continue_bits_count(h);
+    case 3: return angle_new_method(h, p.angle_label_lut);
+    default: return h;
+    }
+}
+
+// Scala Double.toInt: NaN -> 0, saturating, toward zero (PStable:130)
+__device__ inline int32_t d2i_sat(double x)
+{
+    if (x != x) return 0;
+    if (x >= 2147483647.0) return 2147483647;
+    if (x <= -2147483648.0) return (int32_t)0x80000000;
+    return (int32_t)x;
+}
+
+// java.util.Arrays.hashCode over the four big-endian bytes of idx (ByteArrayWrapper.scala:11-14)
+__device__ inline uint32_t hash_int_bytes(uint32_t r, int32_t idx)
+{
+#pragma unroll
+    for (int s = 24; s >= 0; s -= 8) {
+        int32_t byte = (int32_t)(int8_t)(((uint32_t)idx >> s) & 0xff);
+        r = 31u * r + (uint32_t)byte;
+    }
+    return r;
+}
+
+// ---------------------------------------------------------------------------
+// k_hash
+// ---------------------------------------------------------------------------
+// One workgroup hashes a tile of G*QT vectors against all F pool functions,
+// then assembles the L table hashes and sub-index ids of each vector.
+//
+// Thread (fl, qg): function lane fl in [0, FT), query group qg in [0, G),
+// G = 256 / FT.  Each thread carries QT running sums in registers and walks
+// the dimension in order, so every dot product is the exact left-to-right
+// fp64 sum of Sim:40-49 -- bit-identical hash bits, no guard band needed.
+// The pool is read through its transpose fnsT[dim][F] (coalesced across fl,
+// L2-resident); the vector tile sits in LDS and is read as a broadcast.
+template <typename T, int QT>
+__global__ __launch_bounds__(256) void k_hash(const T *__restrict__ X, int64_t x_stride, int64_t n,
+                                              HashParams p, int FT,
+                                              int32_t *__restrict__ hashes, int32_t *__restrict__ parts)
+{
+    extern __shared__ double sm[];
+    const int G = 256 / FT;
+    const int tile = G * QT;
+    double *xs = sm;                          // [tile][dim]
+    double *dots = sm + (size_t)tile * p.dim; // [tile][F]
+    const int tid = threadIdx.x;
+    const int64_t q0 = (int64_t)blockIdx.x * tile;
+
+    for (int idx = tid; idx < tile * p.dim; idx += 256) {
+        int q = idx / p.dim, i = idx - q * p.dim;
+        int64_t row = q0 + q;
+        xs[idx] = row < n ? (double)X[row * x_stride + i] : 0.0;
+    }
+    __syncthreads();
+
+    const int fl = tid % FT, qg = tid / FT;
+    const double *xq = xs + (size_t)qg * QT * p.dim;
+    for (int f0 = 0; f0 < p.F; f0 += FT) {
+        const int f = f0 + fl;
+        if (f < p.F) {
+            double acc[QT];
+#pragma unroll
+            for (int j = 0; j < QT; j++) acc[j] = 0.0;
+            const double *col = p.fnsT + f;
+            for (int i = 0; i < p.dim; i++) {
+                const double a = col[(size_t)i * p.F];
+#pragma unroll
+                for (int j = 0; j < QT; j++) {
+                    const double prod = a * xq[j * p.dim + i];
+                    acc[j] = acc[j] + prod;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < QT; j++) dots[(size_t)(qg * QT + j) * p.F + f] = acc[j];
+        }
+    }
+    __syncthreads();
+
+    for (int idx = tid; idx < tile * p.L; idx += 256) {
+        const int q = idx / p.L, t = idx - q * p.L;
+        const int64_t row = q0 + q;
+        if (row >= n) continue;
+        const double *dq = dots + (size_t)q * p.F;
+        const int32_t *chain = p.chain_fn + (size_t)t * p.m;
+        int32_t h;
+        if (p.family == 0) {
+            // Angle:187-195: result = result << 1 | sign(dot); sign(x) = 0 iff x <= 0 (Angle:184)
+            uint32_t result = 0;
+            for (int j = 0; j < p.m; j++) {
+                const double s = dq[chain[j]];
+                result = (result << 1) | ((s <= 0) ? 0u : 1u);
+            }
+            h = (int32_t)(result << ((32 - p.m) & 31));
+        } else {
+            // PStable:122-143
+            uint32_t r = 1;
+            for (int j = 0; j < p.m; j++) {
+                const int f = chain[j];
+                double v = dq[f] + p.b[f];
+                v = v / (double)p.w[f];
+                r = hash_int_bytes(r, d2i_sat(v));
+            }
+            h = (int32_t)r;
+        }
+        h = apply_type_of_index(h, p);
+        hashes[row * p.L + t] = h;
+
+        // Part:40-59: set bits of h -> 32-dim 0/1 vector -> the table's own
+        // partitioner chain (ascending-bit fp64 sum, Sim:9-27) -> top pb bits.
+        int32_t part = 0;
+        if (p.pb > 0) {
+            const double *pf = p.part_fns + (size_t)t * p.pb * 32;
+            uint32_t presult = 0, pr = 1;
+            for (int j = 0; j < p.pb; j++) {
+                double s = 0.0;
+                for (int i = 0; i < 32; i++)
+                    if (((uint32_t)h >> i) & 1u) s = s + pf[j * 32 + i];
+                if (p.family == 0) {
+                    presult = (presult << 1) | ((s <= 0) ? 0u : 1u);
+                } else {
+                    double v = s + p.part_b[t * p.pb + j];
+                    v = v / (double)p.part_w[t * p.pb + j];
+                    pr = hash_int_bytes(pr, d2i_sat(v));
+                }
+            }
+            int32_t ph = p.family == 0 ? (int32_t)(presult << ((32 - p.pb) & 31)) : (int32_t)pr;
+            ph = apply_type_of_index(ph, p);
+            part = (int32_t)((uint32_t)ph >> ((32 - p.pb) & 31));
+        }
+        if (parts) parts[row * p.L + t] = part;
+    }
+}
+
+void launch_hash(int dtype, const void *X, int64_t x_stride, int64_t n, const HashParams &p,
+                 int32_t *hashes, int32_t *parts, hipStream_t stream)
+{
+    if (n <= 0) return;
+    int FT = p.F <= 64 ? 64 : (p.F <= 128 ? 128 : 256);
+    const int QT = 4;
+    int tile = (256 / FT) * QT;
+    size_t shmem = (size_t)tile * (p.dim + p.F) * sizeof(double);
+    unsigned grid = (unsigned)((n + tile - 1) / tile);
+    if (dtype == 0)
+        hipLaunchKernelGGL((k_hash<float, QT>), dim3(grid), dim3(256), shmem, stream,
+                           (const float *)X, x_stride, n, p, FT, hashes, parts);
+    else
+        hipLaunchKernelGGL((k_hash<double, QT>), dim3(grid), dim3(256), shmem, stream,
+                           (const double *)X, x_stride, n, p, FT, hashes, parts);
+}
+
+size_t hash_shmem_bytes(const HashParams &p)
+{
+    int FT = p.F <= 64 ? 64 : (p.F <= 128 ? 128 : 256);
+    int tile = (256 / FT) * 4;
+    return (size_t)tile * (p.dim + p.F) * sizeof(double);
+}
+
+// ---------------------------------------------------------------------------
+// k_probe
+// ---------------------------------------------------------------------------
+
+// RDT:946-992 on the flattened trie: <= max_level+1 dependent 4-byte reads.
+__device__ inline uint32_t walk(const uint32_t *__restrict__ dnodes, uint32_t root, uint32_t pro,
+                                int max_level, int nbits, int dns)
+{
+    uint32_t node = root;
+    if (node == 0) return NO_LEAF;
+    for (int level = max_level; level >= 0; --level) {
+        const uint32_t slot = (pro >> (level * nbits)) & (uint32_t)(dns - 1);
+        const uint32_t w = dnodes[(size_t)node * dns + slot];
+        if (w == 0) return NO_LEAF;
+        if (w & 1u) return w >> 1;
+        node = w >> 1;
+    }
+    return NO_LEAF;
+}
+
+// RDT:982: candidate == query id is dropped only for ids in the boxed-Integer
+// cache [-128, 127] (reference inequality on java.lang.Integer).
+__device__ inline bool self_excluded(int32_t cand, int32_t qid, int mode)
+{
+    if (cand != qid) return false;
+    if (mode == 1) return true;
+    if (mode == 2) return false;
+    return qid >= -128 && qid <= 127;
+}
+
+// One workgroup per query.  Waves take tables round-robin.  For one table a
+// wave enumerates the sub-indexes within `steps` bit flips of the query's own
+// (RDT:613-621), two per round: lanes 0-31 walk the <= 28 single-bit-flip probes
+// (RDT:753-756; the unflipped hash itself is never probed) of the first, lanes
+// 32-63 of the second.  Probes that end in the same bucket are collapsed with
+// shuffles (the reference concatenates duplicates and takes a Set later,
+// Dense:420), then the wave streams each distinct bucket's ids.
+//
+// MODE 0: count ids only (raw[q], used to size the candidate arena).
+// MODE 1: set a bit per id in an LDS bitmap covering [lo, hi), then emit the
+//         set bits as the query's sorted unique candidate list.
+template <int MODE>
+__global__ __launch_bounds__(1024) void k_probe(ProbeParams p)
+{
+    extern __shared__ uint32_t lds[];
+    __shared__ unsigned long long s_raw;
+    __shared__ uint32_t s_wave_tot[16];
+    __shared__ uint32_t s_emitted;
+
+    const int64_t q = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    const int half = lane >> 5, i = lane & 31;
+    const int32_t qid = p.qids ? p.qids[q] : -1;
+    const int P = 1 << p.pb;
+
+    if (tid == 0) { s_raw = 0; s_emitted = 0; }
+
+    const int64_t range = p.row_end - p.row_begin;
+    const int64_t chunk_bits = (int64_t)p.chunk_words * 32;
+    const int nchunks = MODE == 0 ? 1 : (int)((range + chunk_bits - 1) / chunk_bits);
+    unsigned long long raw_local = 0;
+
+    for (int c = 0; c < nchunks; c++) {
+        const int64_t lo = p.row_begin + (int64_t)c * chunk_bits;
+        const int64_t hi = (lo + chunk_bits < p.row_end) ? lo + chunk_bits : p.row_end;
+        const int nwords = (int)((hi - lo + 31) >> 5);
+        if (MODE == 1) {
+            for (int w = tid; w < nwords; w += blockDim.x) lds[w] = 0;
+        }
+        __syncthreads();
+
+        for (int t = wave; t < p.L; t += nwaves) {
+            const uint32_t h = (uint32_t)p.hashes[q * p.L + t];
+            const int part = p.parts[q * p.L + t];
+            // RDT:753: 32 - numberOfLeadingZeros(h) - 4 probes; negative for 0 <= h < 8
+            const int nprobe = 32 - (h ? __clz(h) : 32) - 4;
+            if (nprobe <= 0) {
+                if (nprobe < 0 && lane == 0 && c == 0 && MODE == 0) atomicAdd(p.short_hash_events, 1ull);
+                continue;
+            }
+            const uint32_t seg = h >> p.bucket_bits;
+            const uint32_t *roots = p.roots + ((size_t)t * P) * p.seg + seg;
+            int pair0 = -1, pair1 = -1;
+            for (int s = 0; s <= P; s++) {
+                if (s < P && __popc((uint32_t)(s ^ part)) <= p.steps) {
+                    if (pair0 < 0) pair0 = s; else pair1 = s;
+                }
+                if ((pair1 >= 0) || (s == P && pair0 >= 0)) {
+                    const int sub = half ? pair1 : pair0;
+                    uint32_t leaf = NO_LEAF;
+                    if (sub >= 0 && i < nprobe)
+                        leaf = walk(p.dnodes, roots[(size_t)sub * p.seg], h ^ (1u << i), p.max_level, p.nbits, p.dns);
+                    // collapse probes that reached the same bucket (same sub-index only:
+                    // buckets of different sub-indexes are disjoint)
+                    bool dup = false;
+                    for (int j = 0; j < nprobe - 1; j++) {
+                        const uint32_t o = __shfl(leaf, (lane & 32) + j);
+                        dup |= (j < i) && (o == leaf);
+                    }
+                    if (dup) leaf = NO_LEAF;
+                    uint32_t beg = 0, end = 0;
+                    if (leaf != NO_LEAF) { beg = p.leaf_off[leaf]; end = p.leaf_off[leaf + 1]; }
+                    if (MODE == 0) {
+                        raw_local += end - beg;
+                    } else {
+                        unsigned long long mask = __ballot(leaf != NO_LEAF);
+                        while (mask) {
+                            const int src = __ffsll((long long)mask) - 1;
+                            mask &= mask - 1;
+                            const uint32_t b = __shfl(beg, src), e = __shfl(end, src);
+                            for (uint32_t k = b + lane; k < e; k += 64) {
+                                const int32_t id = p.ids[k];
+                                if (id >= lo && id < hi && !self_excluded(id, qid, p.exclude_self)) {
+                                    const uint32_t bit = (uint32_t)(id - lo);
+                                    atomicOr(&lds[bit >> 5], 1u << (bit & 31));
+                                }
+                            }
+                        }
+                    }
+                    pair0 = pair1 = -1;
+                }
+            }
+        }
+        if (MODE == 0) break;
+        __syncthreads();
+
+        // emit set bits in ascending order: each wave owns a contiguous block of words
+        const int words_per_wave = (nwords + nwaves - 1) / nwaves;
+        const int wbeg = wave * words_per_wave;
+        const int wend = (wbeg + words_per_wave < nwords) ? wbeg + words_per_wave : nwords;
+        uint32_t cnt = 0;
+        for (int w = wbeg + lane; w < wend; w += 64) cnt += __popc(lds[w]);
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+        if (lane == 0) s_wave_tot[wave] = cnt;
+        __syncthreads();
+        uint32_t base = s_emitted;
+        for (int w = 0; w < wave; w++) base += s_wave_tot[w];
+        int32_t *out = p.cand + p.cand_off[q];
+        for (int w0 = wbeg; w0 < wend; w0 += 64) {
+            const int w = w0 + lane;
+            uint32_t word = (w < wend) ? lds[w] : 0u;
+            uint32_t incl = __popc(word);
+            const uint32_t mine = incl;
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t v = __shfl_up(incl, o);
+                if (lane >= o) incl += v;
+            }
+            uint32_t pos = base + incl - mine;
+            const int32_t idbase = (int32_t)(lo + (int64_t)w * 32);
+            while (word) {
+                const int bpos = __ffs((int)word) - 1;
+                word &= word - 1;
+                out[pos++] = idbase + bpos;
+            }
+            base += __shfl(incl, 63);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t tot = 0;
+            for (int w = 0; w < nwaves; w++) tot += s_wave_tot[w];
+            s_emitted += tot;
+        }
+        __syncthreads();
+    }
+
+    if (MODE == 0) {
+        for (int o = 32; o > 0; o >>= 1) raw_local += __shfl_xor(raw_local, o);
+        if (lane == 0 && raw_local) atomicAdd(&s_raw, raw_local);
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned long long r = s_raw;
+            p.raw[q] = r;
+            p.bound[q] = (int64_t)(r < (unsigned long long)range ? r : (unsigned long long)range);
+        }
+    } else {
+        if (tid == 0) p.cnt[q] = (int32_t)s_emitted;
+    }
+}
+
+void launch_probe(int mode, const ProbeParams &p, int64_t nq, hipStream_t stream)
+{
+    if (nq <= 0) return;
+    if (mode == 0) {
+        hipLaunchKernelGGL((k_probe<0>), dim3((unsigned)nq), dim3(256), 0, stream, p);
+    } else {
+        size_t shmem = (size_t)p.chunk_words * sizeof(uint32_t);
+        hipLaunchKernelGGL((k_probe<1>), dim3((unsigned)nq), dim3(1024), shmem, stream, p);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_scan: off[0] = 0, off[i+1] = off[i] + in[i]   (single workgroup)
+// ---------------------------------------------------------------------------
+template <typename TIN>
+__global__ __launch_bounds__(1024) void k_scan(const TIN *__restrict__ in, int64_t n, int64_t *__restrict__ off)
+{
+    __shared__ int64_t part[1024];
+    const int tid = threadIdx.x;
+    const int64_t per = (n + 1023) / 1024;
+    const int64_t b = tid * per, e = (b + per < n) ? b + per : n;
+    int64_t s = 0;
+    for (int64_t i = b; i < e; i++) s += (int64_t)in[i];
+    part[tid] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        int64_t v = tid >= o ? part[tid - o] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int64_t run = part[tid] - s;
+    for (int64_t i = b; i < e; i++) { off[i] = run; run += (int64_t)in[i]; }
+    if (tid == 1023) off[n] = part[1023];
+}
+
+void launch_scan_i64(const int64_t *in, int64_t n, int64_t *off, hipStream_t stream)
+{
+    hipLaunchKernelGGL((k_scan<int64_t>), dim3(1), dim3(1024), 0, stream, in, n, off);
+}
+void launch_scan_i32(const int32_t *in, int64_t n, int64_t *off, hipStream_t stream)
+{
+    hipLaunchKernelGGL((k_scan<int32_t>), dim3(1), dim3(1024), 0, stream, in, n, off);
+}
+
+// ---------------------------------------------------------------------------
+// k_compact: dst[dst_off[q] + j] = src[src_off[q] + j], j < cnt[q]
+// ---------------------------------------------------------------------------
+__global__ void k_compact(const int32_t *__restrict__ src, const int64_t *__restrict__ src_off,
+                          const int32_t *__restrict__ cnt, const int64_t *__restrict__ dst_off,
+                          int32_t *__restrict__ dst)
+{
+    const int64_t q = blockIdx.x;
+    const int32_t n = cnt[q];
+    const int32_t *s = src + src_off[q];
+    int32_t *d = dst + dst_off[q];
+    for (int32_t j = threadIdx.x; j < n; j += blockDim.x) d[j] = s[j];
+}
+
+void launch_compact(const int32_t *src, const int64_t *src_off, const int32_t *cnt,
+                    const int64_t *dst_off, int32_t *dst, int64_t nq, hipStream_t stream)
+{
+    if (nq <= 0) return;
+    hipLaunchKernelGGL(k_compact, dim3((unsigned)nq), dim3(256), 0, stream, src, src_off, cnt, dst_off, dst);
+}
+
+// ---------------------------------------------------------------------------
+// k_rerank
+// ---------------------------------------------------------------------------
+
+// order of the final list: metric dot = descending inner product (Dense:490),
+// metric l2 = ascending squared distance; equal scores by ascending id.
+template <int METRIC>
+__device__ inline bool better(double sa, int32_t ia, double sb, int32_t ib)
+{
+    if (sa != sb) return METRIC == 0 ? (sa > sb) : (sa < sb);
+    return ia < ib;
+}
+
+template <int METRIC>
+__device__ inline double worst_score()
+{
+    return METRIC == 0 ? -HUGE_VAL : HUGE_VAL;
+}
+
+// A wave keeps its best K entries sorted, entry e in lane e.
+template <int METRIC>
+__device__ inline void topk_insert(double s, int32_t id, double &ls, int32_t &lid, int K, int lane)
+{
+    const bool shift = (lane < K) && better<METRIC>(s, id, ls, lid);
+    const unsigned long long mask = __ballot(shift);
+    if (mask == 0) return;
+    const int pos = __ffsll((long long)mask) - 1;
+    const double ps = __shfl_up(ls, 1);
+    const int32_t pid = __shfl_up(lid, 1);
+    if (lane == pos) { ls = s; lid = id; }
+    else if (lane > pos && lane < K) { ls = ps; lid = pid; }
+}
+
+template <typename T> struct Vec16;
+template <> struct Vec16<float> { typedef float4 type; static constexpr int N = 4; };
+template <> struct Vec16<double> { typedef double2 type; static constexpr int N = 2; };
+
+template <typename T, int METRIC>
+__device__ inline double accum16(const typename Vec16<T>::type &q, const typename Vec16<T>::type &x, double acc);
+
+template <> __device__ inline double accum16<float, 0>(const float4 &q, const float4 &x, double acc)
+{
+    acc = fma((double)q.x, (double)x.x, acc); acc = fma((double)q.y, (double)x.y, acc);
+    acc = fma((double)q.z, (double)x.z, acc); acc = fma((double)q.w, (double)x.w, acc);
+    return acc;
+}
+template <> __device__ inline double accum16<float, 1>(const float4 &q, const float4 &x, double acc)
+{
+    double d0 = (double)q.x - (double)x.x, d1 = (double)q.y - (double)x.y;
+    double d2 = (double)q.z - (double)x.z, d3 = (double)q.w - (double)x.w;
+    acc = fma(d0, d0, acc); acc = fma(d1, d1, acc); acc = fma(d2, d2, acc); acc = fma(d3, d3, acc);
+    return acc;
+}
+template <> __device__ inline double accum16<double, 0>(const double2 &q, const double2 &x, double acc)
+{
+    acc = fma(q.x, x.x, acc); acc = fma(q.y, x.y, acc);
+    return acc;
+}
+template <> __device__ inline double accum16<double, 1>(const double2 &q, const double2 &x, double acc)
+{
+    double d0 = q.x - x.x, d1 = q.y - x.y;
+    acc = fma(d0, d0, acc); acc = fma(d1, d1, acc);
+    return acc;
+}
+
+// One workgroup (4 waves) per query.  A group of LPR lanes owns one candidate
+// row per step: lane gl of the group loads 16-byte pieces gl, gl+LPR, ... of the
+// row (whole rows, consecutive lanes on consecutive 16 B: fully coalesced),
+// accumulates its share of the fp64 score, and the group reduces with
+// shuffles.  UR rows per group are in flight at once.  Scores are fp64 so that
+// the order of near-equal candidates matches an fp64 CPU evaluation.
+template <typename T, int METRIC, int LPR, int NJ, int UR>
+__global__ __launch_bounds__(256) void k_rerank(RerankParams p)
+{
+    typedef typename Vec16<T>::type V;
+    __shared__ double s_score[4 * 64];
+    __shared__ int32_t s_id[4 * 64];
+
+    const int64_t q = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int GPW = 64 / LPR;
+    const int grp = lane / LPR, gl = lane % LPR;
+    const int K = p.k;
+    const int nc = p.chunks16;            // 16-byte pieces per row
+
+    const char *qrow = (const char *)p.Q + (size_t)q * p.q_stride_bytes;
+    V qv[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+        const int c = gl + j * LPR;
+        if (c < nc) qv[j] = *(const V *)(qrow + (size_t)c * 16);
+        else { V z = {}; qv[j] = z; }
+    }
+
+    double ls = worst_score<METRIC>();
+    int32_t lid = 0x7fffffff;
+    double thr_s = ls; int32_t thr_id = lid;
+
+    const int64_t coff = p.cand_off[q];
+    const int32_t cnt = p.cnt ? p.cnt[q] : (int32_t)(p.cand_off[q + 1] - coff);
+    const int32_t *cand = p.cand + coff;
+    const char *base = (const char *)p.base;
+
+    for (int32_t b0 = wave * GPW * UR; b0 < cnt; b0 += 4 * GPW * UR) {
+        int32_t id[UR];
+        V x[UR][NJ];
+#pragma unroll
+        for (int u = 0; u < UR; u++) {
+            const int32_t idx = b0 + u * GPW + grp;
+            id[u] = idx < cnt ? cand[idx] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < UR; u++) {
+            const bool ok = id[u] >= p.row_begin && id[u] < p.row_end;
+            const char *row = base + (size_t)(ok ? (id[u] - p.row_begin) : 0) * p.base_stride_bytes;
+            if (!ok) id[u] = -1;
+#pragma unroll
+            for (int j = 0; j < NJ; j++) {
+                const int c = gl + j * LPR;
+                if (ok && c < nc) x[u][j] = *(const V *)(row + (size_t)c * 16);
+                else { V z = {}; x[u][j] = qv[j]; if (METRIC == 0) x[u][j] = z; }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UR; u++) {
+            double acc = 0.0;
+#pragma unroll
+            for (int j = 0; j < NJ; j++) acc = accum16<T, METRIC>(qv[j], x[u][j], acc);
+#pragma unroll
+            for (int o = LPR / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+            const bool cand_ok = (gl == 0) && (id[u] >= 0) && better<METRIC>(acc, id[u], thr_s, thr_id);
+            unsigned long long m = __ballot(cand_ok);
+            while (m) {
+                const int src = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const double s = __shfl(acc, src);
+                const int32_t sid = __shfl(id[u], src);
+                topk_insert<METRIC>(s, sid, ls, lid, K, lane);
+                thr_s = __shfl(ls, K - 1);
+                thr_id = __shfl(lid, K - 1);
+            }
+        }
+    }
+
+    // merge the four waves' lists through LDS; wave 0 inserts the others' entries
+    s_score[wave * 64 + lane] = ls;
+    s_id[wave * 64 + lane] = lid;
+    __syncthreads();
+    if (wave == 0) {
+        for (int w = 1; w < 4; w++) {
+            for (int e = 0; e < K; e++) {
+                const double s = s_score[w * 64 + e];
+                const int32_t sid = s_id[w * 64 + e];
+                if (sid == 0x7fffffff) break;
+                topk_insert<METRIC>(s, sid, ls, lid, K, lane);
+            }
+        }
+        if (lane < K) {
+            const bool has = lid != 0x7fffffff;
+            p.out_ids[q * K + lane] = has ? lid : -1;
+            p.out_scores[q * K + lane] = has ? ls : nan("");
+        }
+    }
+}
+
+template <typename T, int METRIC>
+static void launch_rerank_tm(const RerankParams &p, int64_t nq, hipStream_t stream)
+{
+    const int nc = p.chunks16;
+    dim3 grid((unsigned)nq), block(256);
+#define DPF_RR(LPR, NJ, UR) hipLaunchKernelGGL((k_rerank<T, METRIC, LPR, NJ, UR>), grid, block, 0, stream, p)
+    if (nc <= 8) DPF_RR(8, 1, 4);
+    else if (nc <= 16) DPF_RR(16, 1, 8);
+    else if (nc <= 32) DPF_RR(32, 1, 8);
+    else if (nc <= 64) DPF_RR(64, 1, 8);
+    else if (nc <= 128) DPF_RR(64, 2, 4);
+    else if (nc <= 192) DPF_RR(64, 3, 4);
+    else if (nc <= 256) DPF_RR(64, 4, 2);
+    else if (nc <= 384) DPF_RR(64, 6, 2);
+    else if (nc <= 512) DPF_RR(64, 8, 1);
+    else DPF_RR(64, 16, 1);
+#undef DPF_RR
+}
+
+int rerank_max_chunks16() { return 1024; }
+
+void launch_rerank(int dtype, int metric, const RerankParams &p, int64_t nq, hipStream_t stream)
+{
+    if (nq <= 0) return;
+    if (dtype == 0) {
+        if (metric == 0) launch_rerank_tm<float, 0>(p, nq, stream);
+        else launch_rerank_tm<float, 1>(p, nq, stream);
+    } else {
+        if (metric == 0) launch_rerank_tm<double, 0>(p, nq, stream);
+        else launch_rerank_tm<double, 1>(p, nq, stream);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_merge_topk: one thread per query merges `parts` sorted lists of k entries
+// ---------------------------------------------------------------------------
+template <int METRIC>
+__global__ void k_merge_topk(const int32_t *__restrict__ in_ids, const double *__restrict__ in_scores,
+                             int parts, int64_t nq, int k, int32_t *__restrict__ out_ids,
+                             double *__restrict__ out_scores)
+{
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    int head[64];
+    for (int s = 0; s < parts; s++) head[s] = 0;
+    for (int e = 0; e < k; e++) {
+        int best = -1;
+        double bs = 0; int32_t bi = 0;
+        for (int s = 0; s < parts; s++) {
+            if (head[s] >= k) continue;
+            const int64_t at = ((int64_t)s * nq + q) * k + head[s];
+            const int32_t id = in_ids[at];
+            if (id < 0) { head[s] = k; continue; }
+            const double sc = in_scores[at];
+            if (best < 0 || better<METRIC>(sc, id, bs, bi)) { best = s; bs = sc; bi = id; }
+        }
+        if (best < 0) { out_ids[q * k + e] = -1; out_scores[q * k + e] = nan(""); }
+        else { out_ids[q * k + e] = bi; out_scores[q * k + e] = bs; head[best]++; }
+    }
+}
+
+void launch_merge_topk(int metric, const int32_t *in_ids, const double *in_scores, int parts,
+                       int64_t nq, int k, int32_t *out_ids, double *out_scores, hipStream_t stream)
+{
+    if (nq <= 0) return;
+    unsigned grid = (unsigned)((nq + 127) / 128);
+    if (metric == 0)
+        hipLaunchKernelGGL((k_merge_topk<0>), dim3(grid), dim3(128), 0, stream, in_ids, in_scores, parts, nq, k, out_ids, out_scores);
+    else
+        hipLaunchKernelGGL((k_merge_topk<1>), dim3(grid), dim3(128), 0, stream, in_ids, in_scores, parts, nq, k, out_ids, out_scores);
+}
+
+// Dynamic LDS above 64 KiB has to be opted into per kernel.
+int configure_kernels()
+{
+    const int max_lds = 160 * 1024;
+    hipError_t e;
+    e = hipFuncSetAttribute((const void *)k_hash<float, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void *)k_hash<double, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void *)k_probe<1>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
+    if (e != hipSuccess) return (int)e;
+    return 0;
+}
+
+// copies rows [n][dim] of T into the padded base store
+template <typename T>
+__global__ void k_copy_rows(const T *__restrict__ src, int64_t n, int dim, T *__restrict__ dst, int64_t dst_stride)
+{
+    const int64_t total = n * dst_stride;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / dst_stride;
+        const int c = (int)(i - r * dst_stride);
+        dst[i] = c < dim ? src[r * dim + c] : (T)0;
+    }
+}
+
+void launch_copy_rows(int dtype, const void *src, int64_t n, int dim, void *dst, int64_t dst_stride, hipStream_t stream)
+{
+    if (n <= 0) return;
+    int64_t total = n * dst_stride;
+    unsigned grid = (unsigned)((total + 255) / 256 < 65535 * 4 ? (total + 255) / 256 : 65535 * 4);
+    if (dtype == 0) hipLaunchKernelGGL((k_copy_rows<float>), dim3(grid), dim3(256), 0, stream, (const float *)src, n, dim, (float *)dst, dst_stride);
+    else hipLaunchKernelGGL((k_copy_rows<double>), dim3(grid), dim3(256), 0, stream, (const double *)src, n, dim, (double *)dst, dst_stride);
+}
+
+}  // namespace dpf

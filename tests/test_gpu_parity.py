@@ -1,0 +1,295 @@
+"""MI355X parity: the HIP path, called through the C ABI, against the CPU oracle."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from similaritysearchbyrdf_amd._lib import DpfIndex, DpfError, DPF_ENOTFIT
+from tests.common import make_problem, assert_same_sets, assert_topk_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def both(params, X, dtype=np.float32, **kw):
+    orc = O.OracleIndex(params)
+    orc.fit(np.asarray(X, dtype=np.float64), threads=8)
+    gpu = DpfIndex(params, dtype=dtype, **kw)
+    gpu.fit(X)
+    return orc, gpu
+
+
+@pytest.mark.parametrize("family,dtype,toi", [
+    ("angle", np.float32, "original"), ("angle", np.float64, "original"),
+    ("pStable", np.float32, "original"), ("pStable", np.float64, "original"),
+    ("angle", np.float32, "sampling"), ("angle", np.float32, "continueBitsCount"),
+    ("angle", np.float32, "angleNewMethod"), ("pStable", np.float32, "sampling"),
+])
+def test_hash_and_partition_bit_exact(family, dtype, toi):
+    params, X, Q, _ = make_problem(n=3000, nq=64, family=family, dtype=dtype, type_of_index=toi)
+    orc = O.OracleIndex(params)
+    gpu = DpfIndex(params, dtype=dtype)
+    h, p = gpu.hash_batch(X)
+    X64 = X.astype(np.float64)
+    want = orc.hashes(X64[:500])
+    assert np.array_equal(h[:500], want)
+    for i in range(0, 500, 7):
+        for t in range(orc.L):
+            assert p[i, t] == orc.partition(t, want[i, t])
+    # every hash of the whole set through the fit path
+    orc.fit(X64)
+    for t in range(orc.L):
+        oh, op = orc.fitted_hashes(t)
+        assert np.array_equal(h[:, t], oh)
+        assert np.array_equal(p[:, t], op)
+
+
+def test_hash_exact_zero_dot_products():
+    # sign(0) = 0 (AngleHashFamily.scala:184): integer data makes exact zeros likely
+    rng = np.random.default_rng(5)
+    dim = 16
+    fns = rng.integers(-2, 3, size=(32, dim)).astype(np.float64)
+    params = dict(family="angle", fns=fns, chain_fn=np.arange(32, dtype=np.int32).reshape(1, 32),
+                  part_fns=rng.integers(-1, 2, size=(1, 3, 32)).astype(np.float64), partition_bits=3)
+    X = rng.integers(-2, 3, size=(4000, dim)).astype(np.float32)
+    orc = O.OracleIndex(params)
+    gpu = DpfIndex(params)
+    h, p = gpu.hash_batch(X)
+    want = orc.hashes(X.astype(np.float64))
+    assert np.array_equal(h, want)
+    assert ((X.astype(np.float64) @ fns.T) == 0).any()
+    for i in range(0, 4000, 13):
+        assert p[i, 0] == orc.partition(0, want[i, 0])
+
+
+CASES = [
+    # n, B, dir, bb, pb, family
+    (2000, 500, 32, 28, 3, "angle"),
+    (2000, 4, 32, 28, 3, "angle"),
+    (6000, 16, 32, 28, 2, "angle"),
+    (6000, 16, 128, 28, 3, "angle"),
+    (6000, 16, 64, 30, 3, "angle"),
+    (6000, 16, 32, 30, 0, "angle"),
+    (6000, 8, 32, 28, 3, "pStable"),
+    (20000, 50, 32, 28, 3, "angle"),
+]
+
+
+@pytest.mark.parametrize("n,B,dns,bb,pb,family", CASES)
+def test_candidate_sets_bit_exact(n, B, dns, bb, pb, family):
+    params, X, Q, pick = make_problem(n=n, nq=48, family=family, bucket_overflow=B, dir_node_size=dns,
+                                      bucket_bits=bb, partition_bits=pb, n_clusters=20, pstable_w=2)
+    orc, gpu = both(params, X)
+    st = gpu.stats()
+    leaves = sum(orc.table_stats(t)[1] for t in range(orc.L))
+    max_leaf = max(orc.table_stats(t)[2] for t in range(orc.L))
+    assert st["num_leaves"] == leaves
+    assert st["max_leaf"] == max_leaf
+    assert st["misflag_events"] == orc.misflag_events
+    # query ids on both sides of the boxed-Integer cache boundary (RDT:982), some equal to indexed ids
+    qids = np.array([0, 5, 127, 128, 129, 1000, -1, -128, -129] + list(pick[9:48]), dtype=np.int32)
+    Qm = Q.copy()
+    Qm[:9] = X[[0, 5, 127, 128, 129, 1000, 3, 4, 6]]    # exact copies: own bucket is reachable
+    for steps in range(0, pb + 1):
+        want = orc.query_batch(qids, Qm.astype(np.float64), steps=steps)
+        got = gpu.query_batch(qids, Qm, steps=steps)
+        assert_same_sets(got, want)
+        if steps == 0:
+            assert want[0][-1] > 0
+    st = gpu.stats()
+    assert st["last_unique_candidates"] == int(want[0][-1])
+    assert st["last_raw_candidates"] >= st["last_unique_candidates"]
+
+
+@pytest.mark.parametrize("mode", ["compat", "always", "never"])
+def test_self_exclusion_modes(mode):
+    params, X, Q, _ = make_problem(n=1500, nq=8, exclude_self=mode, bucket_overflow=30)
+    orc, gpu = both(params, X)
+    qids = np.array([3, 100, 127, 128, 500, 1499, -5, 7], dtype=np.int32)
+    Qm = X[[3, 100, 127, 128, 500, 1499, 5, 7]]
+    want = orc.query_batch(qids, Qm.astype(np.float64), steps=1)
+    got = gpu.query_batch(qids, Qm, steps=1)
+    assert_same_sets(got, want)
+
+
+def test_thread_count_independence_and_idempotence():
+    # TestSingleRDFSuite.scala:36-61: multi-thread result == single-thread result
+    params, X, Q, pick = make_problem(n=5000, nq=32, bucket_overflow=40, table_num=3, permutation_num=2)
+    orc, gpu = both(params, X)
+    w1 = orc.query_batch(pick, Q.astype(np.float64), steps=1, threads=1)
+    w5 = orc.query_batch(pick, Q.astype(np.float64), steps=1, threads=5)
+    w7 = orc.query_batch(pick, Q.astype(np.float64), steps=1, threads=7, mode=1)
+    assert_same_sets(w1, w5)
+    assert_same_sets(w1, w7)
+    g1 = gpu.query_batch(pick, Q, steps=1)
+    g2 = gpu.query_batch(pick, Q, steps=1)
+    assert_same_sets(g1, w1)
+    assert_same_sets(g2, w1)
+
+
+@pytest.mark.parametrize("metric", ["dot", "l2"])
+@pytest.mark.parametrize("dtype,dim", [(np.float32, 100), (np.float64, 100), (np.float32, 50), (np.float32, 128),
+                                        (np.float32, 300), (np.float32, 768), (np.float64, 33)])
+def test_topk_matches_oracle(metric, dtype, dim):
+    params, X, Q, pick = make_problem(n=4000, nq=40, dim=dim, dtype=dtype, bucket_overflow=60, table_num=3,
+                                      permutation_num=1, n_clusters=10)
+    orc, gpu = both(params, X, dtype=dtype, metric=metric, top_k=10)
+    Q64 = Q.astype(np.float64)
+    off, ids = orc.query_batch(pick, Q64, steps=1)
+    want_ids, want_sc = orc.topk(Q64, off, ids, k=10, metric=metric)
+    got_ids, got_sc = gpu.query_topk(pick, Q, steps=1, k=10)
+    assert_topk_equal(got_ids, got_sc, want_ids, want_sc)
+    # the rerank stage alone, over the oracle's candidate lists
+    r_ids, r_sc = gpu.rerank(Q, off, ids, k=10)
+    assert_topk_equal(r_ids, r_sc, want_ids, want_sc)
+    for k in (1, 3, 64):
+        wi, ws = orc.topk(Q64, off, ids, k=k, metric=metric)
+        gi, gs = gpu.rerank(Q, off, ids, k=k)
+        assert_topk_equal(gi, gs, wi, ws)
+
+
+def test_topk_with_duplicate_vectors_breaks_ties_by_id():
+    params, X, Q, pick = make_problem(n=3000, nq=20, bucket_overflow=100, n_clusters=5)
+    X[1000:2000] = X[0:1000]            # every vector twice: exact score ties
+    orc, gpu = both(params, X, metric="l2")
+    Q64 = Q.astype(np.float64)
+    off, ids = orc.query_batch(pick, Q64, steps=2)
+    want = orc.topk(Q64, off, ids, k=10, metric="l2")
+    got = gpu.query_topk(pick, Q, steps=2, k=10)
+    assert np.array_equal(got[0], want[0])
+
+
+def test_row_shards_and_merge():
+    import torch
+    params, X, Q, pick = make_problem(n=6000, nq=24, bucket_overflow=50, table_num=2, permutation_num=2)
+    orc = O.OracleIndex(params)
+    orc.fit(X.astype(np.float64))
+    Q64 = Q.astype(np.float64)
+    off, ids = orc.query_batch(pick, Q64, steps=1)
+    want = orc.topk(Q64, off, ids, k=10, metric="l2")
+    bounds = [(0, 1500), (1500, 3000), (3000, 4500), (4500, -1)]
+    parts_ids, parts_sc = [], []
+    for lo, hi in bounds:
+        g = DpfIndex(params, metric="l2", row_begin=lo, row_end=hi)
+        g.fit(X)
+        so, si = g.query_batch(pick, Q, steps=1)
+        hi_eff = 6000 if hi < 0 else hi
+        for q in range(24):
+            w = ids[off[q]:off[q + 1]]
+            assert np.array_equal(si[so[q]:so[q + 1]], w[(w >= lo) & (w < hi_eff)])
+        pi, ps = g.query_topk(pick, Q, steps=1, k=10)
+        parts_ids.append(pi)
+        parts_sc.append(ps)
+    dev = torch.device("cuda:0")
+    t_ids = torch.from_numpy(np.stack(parts_ids)).to(dev)
+    t_sc = torch.from_numpy(np.stack(parts_sc)).to(dev)
+    o_ids = torch.empty((24, 10), dtype=torch.int32, device=dev)
+    o_sc = torch.empty((24, 10), dtype=torch.float64, device=dev)
+    g.merge_topk_device(t_ids.data_ptr(), t_sc.data_ptr(), 4, 24, 10, o_ids.data_ptr(), o_sc.data_ptr())
+    torch.cuda.synchronize()
+    assert_topk_equal(o_ids.cpu().numpy(), o_sc.cpu().numpy(), want[0], want[1])
+
+
+def test_incremental_fit_equals_one_fit():
+    params, X, Q, pick = make_problem(n=5000, nq=16, bucket_overflow=12)
+    orc = O.OracleIndex(params)
+    orc.fit(X[:2000].astype(np.float64))
+    orc.fit(X[2000:].astype(np.float64))
+    gpu = DpfIndex(params)
+    gpu.fit(X[:2000])
+    gpu.fit(X[2000:3000])
+    gpu.fit(X[3000:])
+    one = DpfIndex(params)
+    one.fit(X)
+    want = orc.query_batch(pick, Q.astype(np.float64), steps=1)
+    assert_same_sets(gpu.query_batch(pick, Q, steps=1), want)
+    assert_same_sets(one.query_batch(pick, Q, steps=1), want)
+    assert gpu.stats()["num_vectors"] == 5000
+
+
+def test_device_entry_point_matches_host_entry_point():
+    import torch
+    params, X, Q, pick = make_problem(n=3000, nq=33, bucket_overflow=25)
+    gpu = DpfIndex(params, metric="l2")
+    gpu.fit(X)
+    hi, hs = gpu.query_topk(pick, Q, steps=1, k=10)
+    dev = torch.device("cuda:0")
+    dq = torch.from_numpy(Q).to(dev)
+    dqid = torch.from_numpy(pick.astype(np.int32)).to(dev)
+    di = torch.empty((33, 10), dtype=torch.int32, device=dev)
+    ds = torch.empty((33, 10), dtype=torch.float64, device=dev)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        gpu.query_topk_device(dqid.data_ptr(), dq.data_ptr(), 33, 1, 10, di.data_ptr(), ds.data_ptr(), s.cuda_stream)
+    s.synchronize()
+    assert np.array_equal(di.cpu().numpy(), hi)
+    assert np.array_equal(ds.cpu().numpy(), hs)
+    ms, by = gpu.last_rerank_profile()
+    assert ms > 0 and by > 0
+
+
+def test_edge_cases():
+    params, X, Q, pick = make_problem(n=300, nq=4)
+    gpu = DpfIndex(params)
+    off = np.zeros(5, dtype=np.int64)
+    with pytest.raises(DpfError) as ei:
+        gpu.query_batch(pick, Q, steps=0)
+    assert ei.value.code == DPF_ENOTFIT          # "need to fit the data first", Dense:422-424
+    gpu.fit(X)
+    o, i = gpu.query_batch(np.zeros(0, dtype=np.int32), np.zeros((0, 100), dtype=np.float32))
+    assert o.tolist() == [0] and i.size == 0
+    # a query far from everything still returns a (possibly empty) sorted unique list
+    far = np.full((1, 100), 1e6, dtype=np.float32)
+    o, i = gpu.query_batch(np.array([9], dtype=np.int32), far, steps=3)
+    assert np.all(np.diff(i) > 0)
+    # empty candidate lists give -1 / NaN padded rows
+    ids, sc = gpu.rerank(Q, np.zeros(5, dtype=np.int64), np.zeros(0, dtype=np.int32), k=5)
+    assert (ids == -1).all() and np.isnan(sc).all()
+    with pytest.raises(DpfError):
+        DpfIndex(dict(params, dir_node_size=48))
+
+
+def test_short_hash_is_counted_not_fatal():
+    # RDT:753: 0 <= hash < 8 makes `new int[negative]` throw in the reference; here
+    # such (query, table) pairs return nothing and are counted
+    fns = np.array([[1.0], [-1.0]])
+    chain = np.array([[1] * 32], dtype=np.int32)       # every bit 0 -> h = 0
+    params = dict(family="angle", fns=fns, chain_fn=chain, part_fns=np.zeros((1, 2, 32)), partition_bits=2,
+                  bucket_overflow=10)
+    X = np.ones((50, 1), dtype=np.float32)
+    orc, gpu = both(params, X)
+    want = orc.query_batch(np.arange(3), np.ones((3, 1)), steps=1)
+    got = gpu.query_batch(np.arange(3), np.ones((3, 1), dtype=np.float32), steps=1)
+    assert_same_sets(got, want)
+    assert want[0][-1] == 0
+    assert gpu.stats()["short_hash_events"] == 3 == orc.short_hash_events
+
+
+def test_full_size_properties():
+    # 1M x 100 (the benchmark's base size): properties that need no oracle run
+    params, X, Q, pick = make_problem(n=1_000_000, nq=512, table_num=1, permutation_num=1, n_clusters=1000,
+                                      gaussian=True)
+    gpu = DpfIndex(params, metric="l2")
+    gpu.fit(X)
+    st = gpu.stats()
+    assert st["num_vectors"] == 1_000_000 and st["num_leaves"] > 1000 and st["max_leaf"] >= 500
+    o0, i0 = gpu.query_batch(pick, Q, steps=0)
+    o1, i1 = gpu.query_batch(pick, Q, steps=1)
+    o3, i3 = gpu.query_batch(pick, Q, steps=3)
+    for q in range(512):
+        a, b, c = i0[o0[q]:o0[q + 1]], i1[o1[q]:o1[q + 1]], i3[o3[q]:o3[q + 1]]
+        assert np.all(np.diff(a) > 0) and np.all(np.diff(b) > 0) and np.all(np.diff(c) > 0)
+        assert np.isin(a, b).all() and np.isin(b, c).all()      # more steps only add sub-indexes
+    ids, sc = gpu.query_topk(pick, Q, steps=1, k=10)
+    for q in range(0, 512, 17):
+        cand = i1[o1[q]:o1[q + 1]]
+        d2 = ((X[cand].astype(np.float64) - Q[q].astype(np.float64)) ** 2).sum(axis=1)
+        order = np.lexsort((cand, d2))[:10]
+        assert np.array_equal(ids[q, :len(order)], cand[order])
+        assert np.allclose(sc[q, :len(order)], d2[order], rtol=1e-9)
+    # the oracle on a 1/5 sample of the same data agrees too
+    orc = O.OracleIndex(params)
+    orc.fit(X[:200_000].astype(np.float64))
+    g2 = DpfIndex(params)
+    g2.fit(X[:200_000])
+    assert_same_sets(g2.query_batch(pick[:64], Q[:64], steps=1),
+                     orc.query_batch(pick[:64], Q[:64].astype(np.float64), steps=1))
+    assert g2.stats()["misflag_events"] == orc.misflag_events
