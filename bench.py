@@ -58,6 +58,20 @@ def workload(name, n, nq):
     return params, X, Q, pick, steps
 
 
+def pmc_traffic(workload_name, n, nq, world):
+    """HBM-side bytes per rerank launch from the committed rocprofv3 PMC passes
+    (FETCH_SIZE doubled as gfx950 needs, plus WRITE_SIZE); None when no pass
+    matches this configuration."""
+    import glob
+    if world != 1 or n != 1_000_000 or nq != 10_000:
+        return None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_pmc_traffic.json" % workload_name)))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        return json.load(f).get("traffic_bytes_per_launch")
+
+
 def ground_truth_l2(torch, dX, dQ, k, chunk=500):
     """Exact top-k by squared L2 distance (fp32 GEMM form); only used to report recall."""
     xn = (dX * dX).sum(dim=1)
@@ -219,7 +233,8 @@ def main():
                        "unique_candidates_per_query_on_rank0": st["last_unique_candidates"] / nq,
                        "misflag_events": st["misflag_events"], "short_hash_events": st["short_hash_events"]},
             "roofline": {"bound": "hbm", "kernel": "k_rerank", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": pmc_traffic(args.workload, n, nq, world),
                          "algorithmic_bytes_per_launch": rr_bytes, "ms_per_launch": rr},
         }
         if world == 1 and not args.no_cpu_baseline:
