@@ -134,7 +134,7 @@ def main():
     args = ap.parse_args()
 
     import torch
-    from similaritysearchbyrdf_amd._lib import DpfIndex
+    from similaritysearchbyrdf_amd.dist import ShardedDpf
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -152,29 +152,21 @@ def main():
     if args.search_steps is not None:
         steps = args.search_steps
     n, nq, k = X.shape[0], Q.shape[0], args.k
-    lo, hi = n * rank // world, n * (rank + 1) // world
-    ix = DpfIndex(params, metric=args.metric, top_k=k, dtype=np.float32, device=local, row_begin=lo, row_end=hi)
+    sharded = ShardedDpf(params, n, metric=args.metric, top_k=k, dtype=np.float32, device=local, rank=rank, world=world)
+    ix = sharded.index
     t0 = time.time()
-    ix.fit(X)
+    sharded.fit(X)
     fit_s = time.time() - t0
 
     dQ = torch.from_numpy(Q).to(dev)
     dqid = torch.from_numpy(pick.astype(np.int32)).to(dev)
     d_ids = torch.empty((nq, k), dtype=torch.int32, device=dev)
     d_sc = torch.empty((nq, k), dtype=torch.float64, device=dev)
-    if world > 1:
-        g_ids = torch.empty((world, nq, k), dtype=torch.int32, device=dev)
-        g_sc = torch.empty((world, nq, k), dtype=torch.float64, device=dev)
-        m_ids = torch.empty((nq, k), dtype=torch.int32, device=dev)
-        m_sc = torch.empty((nq, k), dtype=torch.float64, device=dev)
 
     def step():
-        stream = torch.cuda.current_stream().cuda_stream
-        ix.query_topk_device(dqid.data_ptr(), dQ.data_ptr(), nq, steps, k, d_ids.data_ptr(), d_sc.data_ptr(), stream)
-        if world > 1:
-            dist.all_gather_into_tensor(g_ids, d_ids)
-            dist.all_gather_into_tensor(g_sc, d_sc)
-            ix.merge_topk_device(g_ids.data_ptr(), g_sc.data_ptr(), world, nq, k, m_ids.data_ptr(), m_sc.data_ptr(), stream)
+        # hash -> probe -> dedupe -> rerank on this rank's shard; with N > 1 one all-gather per
+        # array of the partial top-k lists and the merge kernel
+        sharded.query_topk(dqid, dQ, steps, k, d_ids, d_sc, torch.cuda.current_stream().cuda_stream)
 
     def fence():
         if world > 1:
@@ -203,7 +195,7 @@ def main():
         rr_bytes = by
     fence()
     st = ix.stats()
-    final_ids = (m_ids if world > 1 else d_ids).cpu().numpy()
+    final_ids = d_ids.cpu().numpy()
 
     recall = None
     if not args.no_recall and rank == 0:

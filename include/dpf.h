@@ -45,6 +45,9 @@ enum { DPF_INDEX_ORIGINAL = 0, DPF_INDEX_SAMPLING = 1,
 enum { DPF_SELF_COMPAT = 0, DPF_SELF_ALWAYS = 1, DPF_SELF_NEVER = 2 };
 enum { DPF_METRIC_DOT = 0, DPF_METRIC_L2 = 1 };
 enum { DPF_F32 = 0, DPF_F64 = 1 };
+/* DPF_FLAG_HASH_ONLY: the handle only serves dpf_hash_batch (LSH.calculateIndex); the forest
+ * geometry keys are not validated and fit / query calls are refused. */
+enum { DPF_FLAG_HASH_ONLY = 1 };
 
 /* The subset of the reference's Typesafe-Config keys the path consumes
  * (TestSettings.scala:8-45; read at LSH:19-33, Dense:39-58). */
@@ -66,7 +69,7 @@ typedef struct dpf_config {
     int32_t dtype;            /* DPF_F32 / DPF_F64: element type of base and query
                                  vectors at this boundary and in HBM              */
     int32_t device;           /* HIP device ordinal                               */
-    int32_t reserved;
+    int32_t flags;            /* DPF_FLAG_* */
     int64_t row_begin;        /* rerank shard: this handle scores only candidates  */
     int64_t row_end;          /* with row_begin <= id < row_end; row_end < 0 = all */
 } dpf_config;

@@ -24,7 +24,7 @@ class DpfConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "family", "dim", "num_functions", "num_tables", "chain_length", "partition_bits",
         "bucket_bits", "dir_node_size", "bucket_overflow", "type_of_index", "exclude_self",
-        "metric", "top_k", "dtype", "device", "reserved")] + [("row_begin", C.c_int64), ("row_end", C.c_int64)]
+        "metric", "top_k", "dtype", "device", "flags")] + [("row_begin", C.c_int64), ("row_end", C.c_int64)]
 
 
 class DpfStats(C.Structure):
@@ -142,7 +142,7 @@ class DpfIndex:
             dir_node_size=int(p.get("dir_node_size", 32)), bucket_overflow=int(p.get("bucket_overflow", 500)),
             type_of_index=TYPE_OF_INDEX[p.get("type_of_index", "original")],
             exclude_self=SELF[p.get("exclude_self", "compat")], metric=METRIC[metric], top_k=top_k,
-            dtype=DTYPE[self.np_dtype], device=device, reserved=0, row_begin=row_begin, row_end=row_end)
+            dtype=DTYPE[self.np_dtype], device=device, flags=int(p.get('flags', 0)), row_begin=row_begin, row_end=row_end)
         self.dim, self.L, self.pb, self.top_k = d, Lt, pb, top_k
         self.h = C.c_void_p()
         rc = self.L_.dpf_create(C.byref(self.cfg), C.byref(self.h))

@@ -119,11 +119,11 @@ extern "C" int dpf_create(const dpf_config *cfg, dpf_index **out)
     if (cfg->family != DPF_FAMILY_ANGLE && cfg->family != DPF_FAMILY_PSTABLE) why = "family must be angle or pStable";
     else if (cfg->dim < 1 || cfg->num_functions < 1 || cfg->num_tables < 1) why = "dim, num_functions and num_tables must be positive";
     else if (cfg->chain_length < 1 || (cfg->family == DPF_FAMILY_ANGLE && cfg->chain_length > 32)) why = "chain_length must be in [1, 32] for the angle family";
-    else if (cfg->family == DPF_FAMILY_ANGLE && cfg->chain_length != 32)
+    else if (!(cfg->flags & DPF_FLAG_HASH_ONLY) && cfg->family == DPF_FAMILY_ANGLE && cfg->chain_length != 32)
         // RandomDrawTreeMap.java:953 consumes the LOW bits of the hash while angle hashes are
         // left-aligned (AngleHashFamily.scala:194): shorter chains put every id in slot 0.
         why = "the angle family needs chain_length = 32";
-    else if (!g.derive()) why = "unsupported (bucket_bits, dir_node_size, chain_length, partition_bits, bucket_overflow) combination";
+    else if (!(cfg->flags & DPF_FLAG_HASH_ONLY) && !g.derive()) why = "unsupported (bucket_bits, dir_node_size, chain_length, partition_bits, bucket_overflow) combination";
     else if (cfg->dtype != DPF_F32 && cfg->dtype != DPF_F64) why = "dtype must be DPF_F32 or DPF_F64";
     else if (cfg->top_k < 1 || cfg->top_k > 64) why = "top_k must be in [1, 64]";
     else if (cfg->metric != DPF_METRIC_DOT && cfg->metric != DPF_METRIC_L2) why = "metric must be dot or l2";
@@ -277,6 +277,7 @@ static int check_ready(dpf_index *ix, bool need_fit)
 {
     if (!ix->have_family) return fail(ix, DPF_ENOFAMILY, "hash family not set (dpf_set_hash_family)");
     if (ix->cfg.partition_bits > 0 && !ix->have_part) return fail(ix, DPF_ENOFAMILY, "partitioner not set (dpf_set_partitioner)");
+    if (need_fit && (ix->cfg.flags & DPF_FLAG_HASH_ONLY)) return fail(ix, DPF_EINVAL, "this handle was created hash-only");
     if (need_fit && !ix->fitted) return fail(ix, DPF_ENOTFIT, "need to fit the data first");
     return DPF_OK;
 }
@@ -303,6 +304,7 @@ extern "C" int dpf_fit(dpf_index *ix, const void *X, int64_t n)
     int rc = check_ready(ix, false);
     if (rc != DPF_OK) return rc;
     if (n < 0 || (n > 0 && !X)) return fail(ix, DPF_EINVAL, "dpf_fit: bad arguments");
+    if (ix->cfg.flags & DPF_FLAG_HASH_ONLY) return fail(ix, DPF_EINVAL, "dpf_fit: this handle was created hash-only");
     const dpf_config &c = ix->cfg;
     const int L = c.num_tables, d = c.dim;
     const int64_t first = ix->n, total = first + n;

@@ -1,0 +1,85 @@
+"""Row-sharded multi-GPU batch query: one process per GPU, torch.distributed
+(backend "nccl" = RCCL over xGMI; "gloo" for CPU rehearsal).
+
+The forest and the hash family are replicated; base rows are sharded
+contiguously, rank r owning ids [r*N/G, (r+1)*N/G).  Every rank hashes and
+probes the whole query batch, dedupes and reranks only the candidates inside its
+shard, and the per-shard top-k lists are exchanged with one all-gather per
+array and merged (ordering rule of the single-GPU path: score, then id).
+The reference is a single JVM process (its "distribution" is the in-process
+sub-index partitioning of Partitioner.scala:27-64), so there is no reference
+call pattern to mirror here.
+"""
+import numpy as np
+
+
+def shard_bounds(n, world, rank):
+    """Contiguous row shard of rank `rank`: [lo, hi)."""
+    return n * rank // world, n * (rank + 1) // world
+
+
+def merge_topk_host(ids, scores, metric):
+    """Host-side merge of G partial lists [G, nq, k] (ids < 0 = padding): used to
+    rehearse the exchange on CPU tensors (gloo); on GPUs the merge is k_merge_topk."""
+    G, nq, k = ids.shape
+    out_ids = np.full((nq, k), -1, dtype=np.int32)
+    out_sc = np.full((nq, k), np.nan, dtype=np.float64)
+    for q in range(nq):
+        i = ids[:, q, :].reshape(-1)
+        s = scores[:, q, :].reshape(-1)
+        keep = i >= 0
+        i, s = i[keep], s[keep]
+        key = -s if metric == "dot" else s
+        order = np.lexsort((i, key))[:k]
+        out_ids[q, :len(order)] = i[order]
+        out_sc[q, :len(order)] = s[order]
+    return out_ids, out_sc
+
+
+def exchange(local_ids, local_scores, group=None):
+    """all-gather the [nq, k] partial lists of every rank -> ([G, nq, k], [G, nq, k])."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    g_ids = torch.empty((world,) + tuple(local_ids.shape), dtype=local_ids.dtype, device=local_ids.device)
+    g_sc = torch.empty((world,) + tuple(local_scores.shape), dtype=local_scores.dtype, device=local_scores.device)
+    # concatenated-along-dim-0 output form: accepted by both RCCL and gloo
+    dist.all_gather_into_tensor(g_ids.view((-1,) + tuple(local_ids.shape[1:])), local_ids.contiguous(), group=group)
+    dist.all_gather_into_tensor(g_sc.view((-1,) + tuple(local_scores.shape[1:])), local_scores.contiguous(), group=group)
+    return g_ids, g_sc
+
+
+class ShardedDpf:
+    """One rank's share of a row-sharded index on its GPU."""
+
+    def __init__(self, params, n_total, metric="l2", top_k=10, dtype=np.float32, device=0, rank=0, world=1,
+                 group=None):
+        from ._lib import DpfIndex
+        self.rank, self.world, self.group, self.metric = rank, world, group, metric
+        self.lo, self.hi = shard_bounds(n_total, world, rank)
+        self.index = DpfIndex(params, metric=metric, top_k=top_k, dtype=dtype, device=device,
+                              row_begin=self.lo, row_end=self.hi)
+        self._bufs = None
+
+    def fit(self, X):
+        """Every rank sees every row (hashes build the replicated forest); only the shard stays in HBM."""
+        self.index.fit(X)
+
+    def query_topk(self, d_qids, d_Q, steps, k, out_ids, out_scores, stream=None):
+        """Device tensors in, merged device tensors out (asynchronous on `stream`)."""
+        import torch
+        nq = d_Q.shape[0]
+        if self.world == 1:
+            self.index.query_topk_device(d_qids.data_ptr(), d_Q.data_ptr(), nq, steps, k, out_ids.data_ptr(),
+                                         out_scores.data_ptr(), stream)
+            return
+        if self._bufs is None or self._bufs[0].shape != (nq, k):
+            dev = d_Q.device
+            self._bufs = (torch.empty((nq, k), dtype=torch.int32, device=dev),
+                          torch.empty((nq, k), dtype=torch.float64, device=dev))
+        l_ids, l_sc = self._bufs
+        self.index.query_topk_device(d_qids.data_ptr(), d_Q.data_ptr(), nq, steps, k, l_ids.data_ptr(),
+                                     l_sc.data_ptr(), stream)
+        g_ids, g_sc = exchange(l_ids, l_sc, self.group)
+        self.index.merge_topk_device(g_ids.data_ptr(), g_sc.data_ptr(), self.world, nq, k, out_ids.data_ptr(),
+                                     out_scores.data_ptr(), stream)

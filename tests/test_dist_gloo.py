@@ -1,0 +1,80 @@
+"""World-size-2 rehearsal of the row-sharded query on CPU (gloo): shard bounds, the
+all-gather exchange and the merge rule, with the oracle standing in for each
+rank's device stage.  The merged lists must equal the unsharded oracle's."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import oracle as O
+        from similaritysearchbyrdf_amd.dist import shard_bounds, exchange, merge_topk_host
+        from tests.common import make_problem
+        params, X, Q, pick = make_problem(n=3001, nq=21, bucket_overflow=30, table_num=2, permutation_num=2)
+        n = X.shape[0]
+        lo, hi = shard_bounds(n, world, rank)
+        orc = O.OracleIndex(params)
+        orc.fit(X.astype(np.float64), threads=2)
+        Q64 = Q.astype(np.float64)
+        off, ids = orc.query_batch(pick, Q64, steps=1, threads=2)
+        for metric in ("l2", "dot"):
+            # this rank's stage: candidates restricted to its row shard, then its partial top-k
+            loc_off = [0]
+            loc = []
+            for q in range(len(pick)):
+                c = ids[off[q]:off[q + 1]]
+                c = c[(c >= lo) & (c < hi)]
+                loc.append(c)
+                loc_off.append(loc_off[-1] + len(c))
+            loc_ids = np.concatenate(loc) if loc else np.zeros(0, dtype=np.int32)
+            pi, ps = orc.topk(Q64, np.asarray(loc_off), loc_ids, k=10, metric=metric, threads=2)
+            g_ids, g_sc = exchange(torch.from_numpy(pi), torch.from_numpy(ps))
+            assert g_ids.shape == (world, len(pick), 10)
+            m_ids, m_sc = merge_topk_host(g_ids.numpy(), g_sc.numpy(), metric)
+            want_ids, want_sc = orc.topk(Q64, off, ids, k=10, metric=metric, threads=2)
+            assert np.array_equal(m_ids, want_ids), metric
+            assert np.array_equal(np.nan_to_num(m_sc), np.nan_to_num(want_sc)), metric
+        # shard bounds tile the id space exactly
+        b = [shard_bounds(n, world, r) for r in range(world)]
+        assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+        ret[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2])
+def test_sharded_exchange_and_merge_gloo(world):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert [ret.get(r) for r in range(world)] == ["ok"] * world
+
+
+def test_shard_bounds_edge_cases():
+    from similaritysearchbyrdf_amd.dist import shard_bounds, merge_topk_host
+    for n in (0, 1, 7, 8, 1_000_000):
+        for w in (1, 2, 3, 8):
+            b = [shard_bounds(n, w, r) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            assert max(hi - lo for lo, hi in b) - min(hi - lo for lo, hi in b) <= 1
+    # merge: ties by id, padding ignored, fewer than k survivors padded
+    ids = np.array([[[5, 9, -1]], [[2, 7, -1]]], dtype=np.int32)
+    sc = np.array([[[1.0, 3.0, np.nan]], [[1.0, 2.0, np.nan]]])
+    mi, ms = merge_topk_host(ids, sc, "l2")
+    assert mi.tolist() == [[2, 5, 7]] and ms.tolist() == [[1.0, 1.0, 2.0]]
+    mi, ms = merge_topk_host(ids, sc, "dot")
+    assert mi.tolist() == [[9, 7, 2]]
