@@ -124,13 +124,15 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c3")
-    ap.add_argument("--n", type=int, default=1_000_000)
-    ap.add_argument("--nq", type=int, default=10_000)
+    ap.add_argument("--base-rows", dest="n", type=int, default=1_000_000)
+    ap.add_argument("--queries", dest="nq", type=int, default=10_000)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--metric", default="l2", choices=["l2", "dot"])
     ap.add_argument("--search-steps", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-recall", action="store_true")
+    ap.add_argument("--verify", action="store_true", help="rank 0 also runs an unsharded index and compares the merged ids")
+    ap.add_argument("--backend", default="nccl", help="nccl (RCCL, one GPU per rank) or gloo (rehearsal: ranks may share a GPU)")
     args = ap.parse_args()
 
     import torch
@@ -141,12 +143,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
+    if args.backend == "gloo":
+        local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     params, X, Q, pick, steps = workload(args.workload, args.n, args.nq)
     if args.search_steps is not None:
@@ -183,7 +190,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
@@ -197,6 +204,15 @@ def main():
     st = ix.stats()
     final_ids = d_ids.cpu().numpy()
 
+    if args.verify and rank == 0:
+        from similaritysearchbyrdf_amd._lib import DpfIndex
+        full = DpfIndex(params, metric=args.metric, top_k=k, dtype=np.float32, device=local)
+        full.fit(X)
+        want_ids, _ = full.query_topk(pick.astype(np.int32), Q, steps=steps, k=k)
+        if not np.array_equal(want_ids, final_ids):
+            raise SystemExit("verify failed: merged sharded result differs from the unsharded index")
+        print("verify ok: %d-way sharded result equals the unsharded index" % world, file=sys.stderr)
+        full.close()
     recall = None
     if not args.no_recall and rank == 0:
         dX = torch.from_numpy(X).to(dev)

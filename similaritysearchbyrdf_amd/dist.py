@@ -41,6 +41,10 @@ def exchange(local_ids, local_scores, group=None):
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
+    if dist.get_backend(group) == "gloo" and local_ids.is_cuda:
+        # CPU rehearsal of the exchange with device-resident lists (several ranks sharing one GPU)
+        c_ids, c_sc = exchange(local_ids.cpu(), local_scores.cpu(), group)
+        return c_ids.to(local_ids.device), c_sc.to(local_scores.device)
     g_ids = torch.empty((world,) + tuple(local_ids.shape), dtype=local_ids.dtype, device=local_ids.device)
     g_sc = torch.empty((world,) + tuple(local_scores.shape), dtype=local_scores.dtype, device=local_scores.device)
     # concatenated-along-dim-0 output form: accepted by both RCCL and gloo
