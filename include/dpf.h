@@ -47,7 +47,10 @@ enum { DPF_METRIC_DOT = 0, DPF_METRIC_L2 = 1 };
 enum { DPF_F32 = 0, DPF_F64 = 1 };
 /* DPF_FLAG_HASH_ONLY: the handle only serves dpf_hash_batch (LSH.calculateIndex); the forest
  * geometry keys are not validated and fit / query calls are refused. */
-enum { DPF_FLAG_HASH_ONLY = 1 };
+enum { DPF_FLAG_HASH_ONLY = 1,
+/* DPF_FLAG_GATHER_ONLY: always rerank with the per-query gather kernel, never with the
+ * bucket-major scan (same results; for measurement and A/B). */
+       DPF_FLAG_GATHER_ONLY = 2 };
 
 /* The subset of the reference's Typesafe-Config keys the path consumes
  * (TestSettings.scala:8-45; read at LSH:19-33, Dense:39-58). */
@@ -85,6 +88,10 @@ typedef struct dpf_stats {
     int64_t last_raw_candidates; /* last batch: ids visited before set union       */
     int64_t last_unique_candidates; /* last batch: sum of per-query set sizes      */
     double  last_ms_hash, last_ms_probe, last_ms_dedupe, last_ms_rerank;
+    double  last_ms_scan;        /* bucket-major scan kernel of the last top-k batch (0: gather path) */
+    int64_t last_path;           /* rerank path of the last top-k batch: 0 gather, 1 bucket-major */
+    int64_t last_pairs;          /* (query, bucket) incidences of the last bucket-major batch */
+    int64_t last_forwarded;      /* candidates forwarded to the exact rerank by the scan */
     int64_t snapshot_bytes;      /* HBM bytes of the forest snapshot               */
     int64_t base_bytes;          /* HBM bytes of the resident base rows            */
 } dpf_stats;

@@ -31,8 +31,9 @@ class DpfStats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in (
         "num_vectors", "num_dnodes", "num_leaves", "max_leaf", "misflag_events", "short_hash_events",
         "last_raw_candidates", "last_unique_candidates")] + [
-        (n, C.c_double) for n in ("last_ms_hash", "last_ms_probe", "last_ms_dedupe", "last_ms_rerank")] + [
-        ("snapshot_bytes", C.c_int64), ("base_bytes", C.c_int64)]
+        (n, C.c_double) for n in ("last_ms_hash", "last_ms_probe", "last_ms_dedupe", "last_ms_rerank",
+                                  "last_ms_scan")] + [
+        (n, C.c_int64) for n in ("last_path", "last_pairs", "last_forwarded", "snapshot_bytes", "base_bytes")]
 
 
 EXPORTS = (

@@ -60,6 +60,10 @@ struct dpf_index {
     int64_t base_rows = 0;                   // resident rows: ids row_begin .. row_begin+base_rows-1
 
     DevBuf d_roots, d_dnodes, d_leaf_off, d_ids;
+    DevBuf d_tile_leaf, d_tile_row0;         // 64-row tiles of the buckets (bucket-major scan)
+    int64_t ntiles = 0, num_leaves = 0;
+    double maxnorm = 0.0;                    // largest base-row norm seen by dpf_fit
+    bool bucket_major = false;               // the bucket-major rerank applies to this handle
     bool fitted = false;
     dpf_stats st{};
 
@@ -67,9 +71,13 @@ struct dpf_index {
     DevBuf ws_qpad, ws_hashes, ws_parts, ws_raw, ws_bound, ws_off, ws_cnt, ws_arena, ws_misc;
     DevBuf ws_hq, ws_hqids, ws_hids, ws_hscores;     // device copies for the host-pointer entry points
     DevBuf ws_stage;                                  // fit staging
+    DevBuf ws_lq_cnt, ws_lq_off, ws_lq_cursor, ws_leaf_queries, ws_seed_cand, ws_seed_cnt, ws_seed_ids,
+        ws_seed_scores, ws_emit, ws_emit_cnt, ws_flag, ws_qnorm;
+    hipEvent_t ev_scan[2]{};
     unsigned long long *d_short_hash = nullptr;
     int64_t *pinned = nullptr;                        // host-pinned scratch (8 x int64)
     hipEvent_t ev[6]{};
+    int last_path = 0;
     bool profiling = false;
     int64_t last_nq = 0;
     int32_t last_k = 0;
@@ -134,6 +142,11 @@ extern "C" int dpf_create(const dpf_config *cfg, dpf_index **out)
     ix->elem = cfg->dtype == DPF_F32 ? 4 : 8;
     const int64_t per16 = 16 / (int64_t)ix->elem;
     ix->dpad = (cfg->dim + per16 - 1) / per16 * per16;
+    if (cfg->dtype == DPF_F32 && !(cfg->flags & DPF_FLAG_GATHER_ONLY) && !getenv("DPF_GATHER_ONLY")) {
+        // rows padded to a piece count the bucket-major scan is instantiated for
+        const int nc = leafscan_padded_chunks((int)(ix->dpad / 4));
+        if (nc > 0) { ix->dpad = (int64_t)nc * 4; ix->bucket_major = true; }
+    }
     if (ix->dpad * (int64_t)ix->elem / 16 > rerank_max_chunks16()) { delete ix; return fail(nullptr, DPF_EINVAL, "dpf_create: dim too large for the rerank kernel"); }
     resolve_rows(ix);
 
@@ -147,6 +160,7 @@ extern "C" int dpf_create(const dpf_config *cfg, dpf_index **out)
     if (e == hipSuccess) e = hipMemset(ix->d_short_hash, 0, sizeof(unsigned long long));
     if (e == hipSuccess) e = hipHostMalloc((void **)&ix->pinned, 8 * sizeof(int64_t), hipHostMallocDefault);
     for (int i = 0; i < 6 && e == hipSuccess; i++) e = hipEventCreate(&ix->ev[i]);
+    for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipEventCreate(&ix->ev_scan[i]);
     if (e != hipSuccess) {
         std::string m = std::string("dpf_create: ") + hipGetErrorString(e);
         delete ix;
@@ -183,6 +197,11 @@ extern "C" void dpf_destroy(dpf_index *ix)
     if (ix->d_short_hash) (void)hipFree(ix->d_short_hash);
     if (ix->pinned) (void)hipHostFree(ix->pinned);
     for (int i = 0; i < 6; i++) if (ix->ev[i]) (void)hipEventDestroy(ix->ev[i]);
+    for (int i = 0; i < 2; i++) if (ix->ev_scan[i]) (void)hipEventDestroy(ix->ev_scan[i]);
+    DevBuf *more[] = {&ix->d_tile_leaf, &ix->d_tile_row0, &ix->ws_lq_cnt, &ix->ws_lq_off, &ix->ws_lq_cursor, &ix->ws_leaf_queries,
+                      &ix->ws_seed_cand, &ix->ws_seed_cnt, &ix->ws_seed_ids, &ix->ws_seed_scores, &ix->ws_emit, &ix->ws_emit_cnt,
+                      &ix->ws_flag, &ix->ws_qnorm};
+    for (DevBuf *b : more) b->release();
     delete ix;
 }
 
@@ -282,9 +301,31 @@ static int check_ready(dpf_index *ix, bool need_fit)
     return DPF_OK;
 }
 
-static int upload_snapshot(dpf_index *ix, const ForestSnapshot &s)
+static int upload_snapshot(dpf_index *ix, ForestSnapshot &s)
 {
     int rc;
+    // a row-sharded handle keeps only its own ids in the buckets: the trie is replicated,
+    // the bucket contents are not
+    const int64_t lo = ix->row_begin, hi = std::min<int64_t>(ix->row_end, ix->n);
+    if (lo > 0 || hi < ix->n) {
+        std::vector<int32_t> ids;
+        std::vector<uint32_t> off(s.leaf_off.size(), 0u);
+        ids.reserve(s.ids.size() / 2 + 16);
+        for (size_t l = 0; l + 1 < s.leaf_off.size(); l++) {
+            for (uint32_t k = s.leaf_off[l]; k < s.leaf_off[l + 1]; k++)
+                if (s.ids[k] >= lo && s.ids[k] < hi) ids.push_back(s.ids[k]);
+            off[l + 1] = (uint32_t)ids.size();
+        }
+        s.ids.swap(ids);
+        s.leaf_off.swap(off);
+    }
+    std::vector<uint32_t> tile_leaf, tile_row0;
+    for (size_t l = 0; l + 1 < s.leaf_off.size(); l++)
+        for (uint32_t r = 0; r < s.leaf_off[l + 1] - s.leaf_off[l]; r += 64) { tile_leaf.push_back((uint32_t)l); tile_row0.push_back(r); }
+    ix->ntiles = (int64_t)tile_leaf.size();
+    ix->num_leaves = (int64_t)s.leaf_off.size() - 1;
+    if ((rc = upload(ix, ix->d_tile_leaf, tile_leaf)) != DPF_OK) return rc;
+    if ((rc = upload(ix, ix->d_tile_row0, tile_row0)) != DPF_OK) return rc;
     if ((rc = upload(ix, ix->d_roots, s.roots)) != DPF_OK) return rc;
     if ((rc = upload(ix, ix->d_dnodes, s.dnodes)) != DPF_OK) return rc;
     if ((rc = upload(ix, ix->d_leaf_off, s.leaf_off)) != DPF_OK) return rc;
@@ -328,6 +369,17 @@ extern "C" int dpf_fit(dpf_index *ix, const void *X, int64_t n)
     }
     ix->h_hashes.resize((size_t)total * L);
     ix->h_parts.resize((size_t)total * L);
+    if (ix->bucket_major && c.metric == DPF_METRIC_DOT) {
+        // bound of the fp32 filter's rounding error for inner products (dtype is f32 here)
+        const float *xf = (const float *)X;
+        double mx = ix->maxnorm * ix->maxnorm;
+        for (int64_t i = 0; i < n; i++) {
+            double sq = 0;
+            for (int k = 0; k < d; k++) sq += (double)xf[i * d + k] * (double)xf[i * d + k];
+            mx = std::max(mx, sq);
+        }
+        ix->maxnorm = std::sqrt(mx);
+    }
 
     const int64_t batch = 1 << 17;
     HIPCHECK(ix, ix->ws_stage.ensure((size_t)std::min<int64_t>(batch, std::max<int64_t>(n, 1)) * d * ix->elem));
@@ -416,6 +468,8 @@ static void fill_probe_params(dpf_index *ix, ProbeParams &pp, const int32_t *d_q
     pp.cand_off = ix->ws_off.as<int64_t>();
     pp.cand = ix->ws_arena.as<int32_t>();
     pp.cnt = ix->ws_cnt.as<int32_t>();
+    pp.lq_cnt = nullptr; pp.lq_off = nullptr; pp.lq_cursor = nullptr; pp.leaf_queries = nullptr;
+    pp.seed_cand = nullptr; pp.seed_cnt = nullptr; pp.seed_cap = 0;
 }
 
 // hash -> count -> scan -> (sync: arena size) -> dedupe.  Leaves the per-query
@@ -463,8 +517,112 @@ static void fill_rerank_params(dpf_index *ix, RerankParams &rp, const void *d_Qp
     rp.k = k;
     rp.row_begin = ix->row_begin;
     rp.row_end = ix->row_begin + ix->base_rows;
-    rp.cand_off = off; rp.cnt = cnt; rp.cand = cand;
+    rp.cand_off = off; rp.cnt = cnt; rp.cand = cand; rp.cand_stride = 0;
     rp.out_ids = d_ids; rp.out_scores = d_scores;
+}
+
+static const int32_t SEED_CAP = 1024;     // seed sample per query (ids from table 0's buckets)
+// forwarded candidates per query before the gather path takes over (DPF_EMIT_CAP overrides, for tests)
+static int32_t emit_cap_setting()
+{
+    const char *e = getenv("DPF_EMIT_CAP");
+    int v = e ? atoi(e) : 2048;
+    return v < 1 ? 1 : v;
+}
+
+// Bucket-major rerank: hash -> count + (query, bucket) histogram -> scan -> bucket->queries lists
+// + seed lists -> exact top-k of the seeds (thresholds) -> bucket-major fp32 filter -> exact
+// fp64 rerank of the forwarded candidates.  Sets *done = false (nothing written) when a query
+// forwarded more than EMIT_CAP candidates; the caller then runs the gather path.
+static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const void *qpad, int64_t qstride, int64_t nq,
+                                 int32_t steps, int32_t k, int32_t *d_ids, double *d_scores, hipStream_t stream, bool *done)
+{
+    *done = false;
+    const int32_t EMIT_CAP = emit_cap_setting();
+    const int L = ix->cfg.num_tables;
+    const int64_t nl = ix->num_leaves;
+    HIPCHECK(ix, ix->ws_hashes.ensure((size_t)nq * L * 4));
+    HIPCHECK(ix, ix->ws_parts.ensure((size_t)nq * L * 4));
+    HIPCHECK(ix, ix->ws_raw.ensure((size_t)nq * 8));
+    HIPCHECK(ix, ix->ws_bound.ensure((size_t)nq * 8));
+    HIPCHECK(ix, ix->ws_lq_cnt.ensure((size_t)(nl + 1) * 4));
+    HIPCHECK(ix, ix->ws_lq_cursor.ensure((size_t)(nl + 1) * 4));
+    HIPCHECK(ix, ix->ws_lq_off.ensure((size_t)(nl + 2) * 8));
+    HIPCHECK(ix, ix->ws_seed_cand.ensure((size_t)nq * SEED_CAP * 4));
+    HIPCHECK(ix, ix->ws_seed_cnt.ensure((size_t)nq * 4));
+    HIPCHECK(ix, ix->ws_seed_ids.ensure((size_t)nq * k * 4));
+    HIPCHECK(ix, ix->ws_seed_scores.ensure((size_t)nq * k * 8));
+    HIPCHECK(ix, ix->ws_emit.ensure((size_t)nq * EMIT_CAP * 4));
+    HIPCHECK(ix, ix->ws_emit_cnt.ensure((size_t)nq * 4));
+    HIPCHECK(ix, ix->ws_flag.ensure(16));
+    HIPCHECK(ix, ix->ws_qnorm.ensure((size_t)nq * 4));
+
+    if (ix->profiling) HIPCHECK(ix, hipEventRecord(ix->ev[0], stream));
+    launch_hash(ix->cfg.dtype, qpad, qstride, nq, ix->hp, ix->ws_hashes.as<int32_t>(), ix->ws_parts.as<int32_t>(), stream);
+    if (ix->profiling) HIPCHECK(ix, hipEventRecord(ix->ev[1], stream));
+    HIPCHECK(ix, hipMemsetAsync(ix->ws_lq_cnt.p, 0, (size_t)(nl + 1) * 4, stream));
+    HIPCHECK(ix, hipMemsetAsync(ix->ws_lq_cursor.p, 0, (size_t)(nl + 1) * 4, stream));
+    HIPCHECK(ix, hipMemsetAsync(ix->ws_emit_cnt.p, 0, (size_t)nq * 4, stream));
+    HIPCHECK(ix, hipMemsetAsync(ix->ws_flag.p, 0, 16, stream));
+    ProbeParams pp;
+    fill_probe_params(ix, pp, d_qids, steps);
+    pp.lq_cnt = ix->ws_lq_cnt.as<uint32_t>();
+    launch_probe(0, pp, nq, stream);
+    launch_scan_i32(ix->ws_lq_cnt.as<int32_t>(), nl, ix->ws_lq_off.as<int64_t>(), stream);
+    HIPCHECK(ix, hipMemcpyAsync(ix->pinned, ix->ws_lq_off.as<int64_t>() + nl, 8, hipMemcpyDeviceToHost, stream));
+    HIPCHECK(ix, hipStreamSynchronize(stream));
+    const int64_t pairs = ix->pinned[0];
+    HIPCHECK(ix, ix->ws_leaf_queries.ensure((size_t)std::max<int64_t>(pairs, 1) * 4));
+    pp.lq_off = ix->ws_lq_off.as<int64_t>();
+    pp.lq_cursor = ix->ws_lq_cursor.as<uint32_t>();
+    pp.leaf_queries = ix->ws_leaf_queries.as<int32_t>();
+    pp.seed_cand = ix->ws_seed_cand.as<int32_t>();
+    pp.seed_cnt = ix->ws_seed_cnt.as<int32_t>();
+    pp.seed_cap = SEED_CAP;
+    launch_probe(2, pp, nq, stream);
+    if (ix->profiling) HIPCHECK(ix, hipEventRecord(ix->ev[2], stream));
+
+    // thresholds: exact top-k of each query's seed sample
+    RerankParams rp;
+    fill_rerank_params(ix, rp, qpad, k, nullptr, ix->ws_seed_cnt.as<int32_t>(), ix->ws_seed_cand.as<int32_t>(),
+                       ix->ws_seed_ids.as<int32_t>(), ix->ws_seed_scores.as<double>());
+    rp.cand_stride = SEED_CAP;
+    launch_rerank(ix->cfg.dtype, ix->cfg.metric, rp, nq, stream);
+    if (ix->cfg.metric == DPF_METRIC_DOT) launch_qnorm((const float *)qpad, ix->dpad, nq, ix->ws_qnorm.as<float>(), stream);
+
+    LeafScanParams lp;
+    lp.tile_leaf = ix->d_tile_leaf.as<uint32_t>(); lp.tile_row0 = ix->d_tile_row0.as<uint32_t>(); lp.ntiles = ix->ntiles;
+    lp.leaf_off = ix->d_leaf_off.as<uint32_t>(); lp.ids = ix->d_ids.as<int32_t>();
+    lp.lq_off = ix->ws_lq_off.as<int64_t>(); lp.leaf_queries = ix->ws_leaf_queries.as<int32_t>();
+    lp.base = ix->d_base.as<float>(); lp.base_stride = ix->dpad;
+    lp.row_begin = ix->row_begin; lp.row_end = ix->row_begin + ix->base_rows;
+    lp.Q = (const float *)qpad; lp.q_stride = ix->dpad;
+    lp.qids = d_qids; lp.exclude_self = ix->cfg.exclude_self;
+    lp.seed_scores = ix->ws_seed_scores.as<double>(); lp.seed_ids = ix->ws_seed_ids.as<int32_t>(); lp.k = k;
+    lp.delta = (float)((double)(ix->dpad + 8) * std::ldexp(1.0, -23));
+    lp.maxnorm = (float)(ix->maxnorm * 1.0001);
+    lp.qnorm = ix->ws_qnorm.as<float>();
+    lp.emit = ix->ws_emit.as<int32_t>(); lp.emit_cnt = ix->ws_emit_cnt.as<int32_t>(); lp.emit_cap = EMIT_CAP;
+    HIPCHECK(ix, hipEventRecord(ix->ev_scan[0], stream));
+    launch_leafscan(ix->cfg.metric, (int)(ix->dpad / 4), lp, stream);
+    HIPCHECK(ix, hipEventRecord(ix->ev_scan[1], stream));
+    launch_overflow_flag(ix->ws_emit_cnt.as<int32_t>(), nq, EMIT_CAP, ix->ws_flag.as<int32_t>(), stream);
+    HIPCHECK(ix, hipMemcpyAsync(ix->pinned + 1, ix->ws_flag.p, 4, hipMemcpyDeviceToHost, stream));
+    HIPCHECK(ix, hipStreamSynchronize(stream));
+    ix->st.last_pairs = pairs;
+    if ((int32_t)(ix->pinned[1] & 0xffffffff) != 0) return DPF_OK;     // overflow: gather path decides
+
+    fill_rerank_params(ix, rp, qpad, k, nullptr, ix->ws_emit_cnt.as<int32_t>(), ix->ws_emit.as<int32_t>(), d_ids, d_scores);
+    rp.cand_stride = EMIT_CAP;
+    HIPCHECK(ix, hipEventRecord(ix->ev[4], stream));
+    launch_rerank(ix->cfg.dtype, ix->cfg.metric, rp, nq, stream);
+    HIPCHECK(ix, hipEventRecord(ix->ev[5], stream));
+    HIPCHECK(ix, hipGetLastError());
+    ix->last_nq = nq;
+    ix->last_valid = true;
+    ix->last_path = 1;
+    *done = true;
+    return DPF_OK;
 }
 
 extern "C" int dpf_query_topk_device(dpf_index *ix, const int32_t *d_qids, const void *d_Q, int64_t nq,
@@ -479,8 +637,14 @@ extern "C" int dpf_query_topk_device(dpf_index *ix, const int32_t *d_qids, const
     hipStream_t stream = (hipStream_t)stream_;
     HIPCHECK(ix, hipSetDevice(ix->cfg.device));
     const void *qpad; int64_t qstride;
-    // the rerank kernel reads whole 16-byte pieces, so it always gets padded rows
+    // the rerank kernels read whole 16-byte pieces, so they always get padded rows
     if ((rc = pad_queries(ix, d_Q, nq, stream, &qpad, &qstride)) != DPF_OK) return rc;
+    ix->last_k = k;
+    if (ix->bucket_major && ix->ntiles > 0) {
+        bool done = false;
+        if ((rc = run_topk_bucket_major(ix, d_qids, qpad, qstride, nq, steps, k, d_ids, d_scores, stream, &done)) != DPF_OK) return rc;
+        if (done) return DPF_OK;
+    }
     if ((rc = run_probe(ix, d_qids, qpad, qstride, nq, steps, stream)) != DPF_OK) return rc;
     RerankParams rp;
     fill_rerank_params(ix, rp, qpad, k, ix->ws_off.as<int64_t>(), ix->ws_cnt.as<int32_t>(), ix->ws_arena.as<int32_t>(), d_ids, d_scores);
@@ -488,7 +652,7 @@ extern "C" int dpf_query_topk_device(dpf_index *ix, const int32_t *d_qids, const
     launch_rerank(ix->cfg.dtype, ix->cfg.metric, rp, nq, stream);
     HIPCHECK(ix, hipEventRecord(ix->ev[5], stream));
     HIPCHECK(ix, hipGetLastError());
-    ix->last_k = k;
+    ix->last_path = 0;
     return DPF_OK;
 }
 
@@ -647,7 +811,8 @@ static int last_totals(dpf_index *ix, int64_t *raw_total, int64_t *uniq_total)
     std::vector<unsigned long long> raw((size_t)ix->last_nq);
     std::vector<int32_t> cnt((size_t)ix->last_nq);
     HIPCHECK(ix, hipMemcpy(raw.data(), ix->ws_raw.p, raw.size() * 8, hipMemcpyDeviceToHost));
-    HIPCHECK(ix, hipMemcpy(cnt.data(), ix->ws_cnt.p, cnt.size() * 4, hipMemcpyDeviceToHost));
+    // gather path: per-query set sizes; bucket-major path: candidates forwarded to the exact rerank
+    HIPCHECK(ix, hipMemcpy(cnt.data(), ix->last_path == 1 ? ix->ws_emit_cnt.p : ix->ws_cnt.p, cnt.size() * 4, hipMemcpyDeviceToHost));
     for (auto v : raw) *raw_total += (int64_t)v;
     for (auto v : cnt) *uniq_total += v;
     return DPF_OK;
@@ -663,6 +828,15 @@ extern "C" int dpf_get_stats(dpf_index *ix, dpf_stats *out)
     ix->st.short_hash_events = (int64_t)sh;
     int rc = last_totals(ix, &ix->st.last_raw_candidates, &ix->st.last_unique_candidates);
     if (rc != DPF_OK) return rc;
+    ix->st.last_path = ix->last_valid ? ix->last_path : 0;
+    ix->st.last_forwarded = 0;
+    ix->st.last_ms_scan = 0;
+    if (ix->last_valid && ix->last_path == 1) {
+        ix->st.last_forwarded = ix->st.last_unique_candidates;
+        ix->st.last_unique_candidates = 0;          // the sets are not materialised on this path
+        float t = 0;
+        if (hipEventElapsedTime(&t, ix->ev_scan[0], ix->ev_scan[1]) == hipSuccess) ix->st.last_ms_scan = t;
+    }
     if (ix->profiling && ix->last_valid) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, ix->ev[0], ix->ev[1]) == hipSuccess) ix->st.last_ms_hash = ms;
@@ -681,7 +855,8 @@ extern "C" int dpf_last_rerank_profile(dpf_index *ix, double *ms, int64_t *algor
     HIPCHECK(ix, hipSetDevice(ix->cfg.device));
     HIPCHECK(ix, hipEventSynchronize(ix->ev[5]));
     float t = 0;
-    HIPCHECK(ix, hipEventElapsedTime(&t, ix->ev[4], ix->ev[5]));
+    if (ix->last_path == 1) HIPCHECK(ix, hipEventElapsedTime(&t, ix->ev_scan[0], ix->ev_scan[1]));
+    else HIPCHECK(ix, hipEventElapsedTime(&t, ix->ev[4], ix->ev[5]));
     int64_t raw = 0, uniq = 0;
     int rc = last_totals(ix, &raw, &uniq);
     if (rc != DPF_OK) return rc;

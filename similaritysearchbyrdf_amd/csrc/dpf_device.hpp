@@ -44,10 +44,46 @@ struct ProbeParams {
     unsigned long long *raw;  // [nq] ids visited (duplicates included)
     int64_t *bound;           // [nq] min(raw, rows in shard)
     unsigned long long *short_hash_events;
+    uint32_t *lq_cnt;         // [num_leaves] optional: (query, bucket) incidence histogram
     // mode 1 inputs / outputs
     const int64_t *cand_off;  // [nq + 1] exclusive scan of bound
     int32_t *cand;            // candidate arena
     int32_t *cnt;             // [nq] set sizes
+    // mode 2 (bucket -> queries lists + per-query seed candidates)
+    const int64_t *lq_off;    // [num_leaves + 1] exclusive scan of lq_cnt
+    uint32_t *lq_cursor;      // [num_leaves] zeroed
+    int32_t *leaf_queries;    // [total pairs]
+    int32_t *seed_cand;       // [nq][seed_cap] ids from table 0's buckets
+    int32_t *seed_cnt;        // [nq]
+    int32_t seed_cap;
+};
+
+// Bucket-major scan: every touched bucket's rows are loaded once and scored
+// against all the queries that probe that bucket.
+struct LeafScanParams {
+    const uint32_t *tile_leaf;   // [ntiles] bucket of each 64-row tile
+    const uint32_t *tile_row0;   // [ntiles] first row of the tile inside its bucket
+    int64_t ntiles;
+    const uint32_t *leaf_off;
+    const int32_t *ids;
+    const int64_t *lq_off;
+    const int32_t *leaf_queries;
+    const float *base;           // padded rows of the resident shard
+    int64_t base_stride;         // floats
+    int64_t row_begin, row_end;
+    const float *Q;              // padded query rows
+    int64_t q_stride;            // floats
+    const int32_t *qids;
+    int32_t exclude_self;
+    const double *seed_scores;   // [nq][k] exact top-k of the seed sample
+    const int32_t *seed_ids;     // [nq][k]
+    int32_t k;
+    float delta;                 // relative error bound of the fp32 score
+    float maxnorm;               // largest base-row norm (dot metric slack)
+    const float *qnorm;          // [nq] query norms (dot metric slack)
+    int32_t *emit;               // [nq][emit_cap]
+    int32_t *emit_cnt;           // [nq] may exceed emit_cap: overflow
+    int32_t emit_cap;
 };
 
 struct RerankParams {
@@ -58,8 +94,9 @@ struct RerankParams {
     int32_t chunks16;         // 16-byte pieces per padded row
     int32_t k;
     int64_t row_begin, row_end;
-    const int64_t *cand_off;  // [nq + 1]
+    const int64_t *cand_off;  // [nq + 1]; nullptr: candidate lists sit at q * cand_stride
     const int32_t *cnt;       // [nq] or nullptr (then cand_off[q+1]-cand_off[q])
+    int64_t cand_stride;      // used when cand_off is nullptr; cnt is clamped to it
     const int32_t *cand;
     int32_t *out_ids;         // [nq][k]
     double *out_scores;       // [nq][k]
@@ -69,6 +106,10 @@ void launch_hash(int dtype, const void *X, int64_t x_stride, int64_t n, const Ha
                  int32_t *hashes, int32_t *parts, hipStream_t stream);
 size_t hash_shmem_bytes(const HashParams &p);
 void launch_probe(int mode, const ProbeParams &p, int64_t nq, hipStream_t stream);
+void launch_leafscan(int metric, int chunks16, const LeafScanParams &p, hipStream_t stream);
+int leafscan_padded_chunks(int nc);
+void launch_qnorm(const float *Q, int64_t q_stride, int64_t nq, float *out, hipStream_t stream);
+void launch_overflow_flag(const int32_t *emit_cnt, int64_t nq, int32_t cap, int32_t *flag, hipStream_t stream);
 void launch_scan_i64(const int64_t *in, int64_t n, int64_t *off, hipStream_t stream);
 void launch_scan_i32(const int32_t *in, int64_t n, int64_t *off, hipStream_t stream);
 void launch_compact(const int32_t *src, const int64_t *src_off, const int32_t *cnt,

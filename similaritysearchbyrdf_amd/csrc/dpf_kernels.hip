@@ -275,9 +275,12 @@ __device__ inline bool self_excluded(int32_t cand, int32_t qid, int mode)
 // shuffles (the reference concatenates duplicates and takes a Set later,
 // Dense:420), then the wave streams each distinct bucket's ids.
 //
-// MODE 0: count ids only (raw[q], used to size the candidate arena).
+// MODE 0: count ids only (raw[q], used to size the candidate arena); optionally
+//         histogram the (query, bucket) incidences per bucket.
 // MODE 1: set a bit per id in an LDS bitmap covering [lo, hi), then emit the
 //         set bits as the query's sorted unique candidate list.
+// MODE 2: append the query to the list of every bucket it reaches, and copy the
+//         ids of table 0's buckets into the query's seed list.
 template <int MODE>
 __global__ __launch_bounds__(1024) void k_probe(ProbeParams p)
 {
@@ -285,6 +288,7 @@ __global__ __launch_bounds__(1024) void k_probe(ProbeParams p)
     __shared__ unsigned long long s_raw;
     __shared__ uint32_t s_wave_tot[16];
     __shared__ uint32_t s_emitted;
+    __shared__ uint32_t s_seed;
 
     const int64_t q = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
@@ -292,11 +296,11 @@ __global__ __launch_bounds__(1024) void k_probe(ProbeParams p)
     const int32_t qid = p.qids ? p.qids[q] : -1;
     const int P = 1 << p.pb;
 
-    if (tid == 0) { s_raw = 0; s_emitted = 0; }
+    if (tid == 0) { s_raw = 0; s_emitted = 0; s_seed = 0; }
 
     const int64_t range = p.row_end - p.row_begin;
     const int64_t chunk_bits = (int64_t)p.chunk_words * 32;
-    const int nchunks = MODE == 0 ? 1 : (int)((range + chunk_bits - 1) / chunk_bits);
+    const int nchunks = MODE != 1 ? 1 : (int)((range + chunk_bits - 1) / chunk_bits);
     unsigned long long raw_local = 0;
 
     for (int c = 0; c < nchunks; c++) {
@@ -341,6 +345,34 @@ __global__ __launch_bounds__(1024) void k_probe(ProbeParams p)
                     if (leaf != NO_LEAF) { beg = p.leaf_off[leaf]; end = p.leaf_off[leaf + 1]; }
                     if (MODE == 0) {
                         raw_local += end - beg;
+                        if (p.lq_cnt && end > beg) atomicAdd(&p.lq_cnt[leaf], 1u);
+                    } else if (MODE == 2) {
+                        if (end > beg) {
+                            const uint32_t pos = atomicAdd(&p.lq_cursor[leaf], 1u);
+                            p.leaf_queries[p.lq_off[leaf] + pos] = (int32_t)q;
+                        }
+                        // seed sample: ids of the first buckets any wave reaches, up to seed_cap
+                        // (duplicates across tables are harmless: the exact rerank keeps one)
+                        unsigned long long mask = __ballot(end > beg);
+                        while (mask && s_seed < (uint32_t)p.seed_cap) {
+                            const int src = __ffsll((long long)mask) - 1;
+                            mask &= mask - 1;
+                            const uint32_t b = __shfl(beg, src), e = __shfl(end, src);
+                            for (uint32_t k0 = b; k0 < e; k0 += 64) {
+                                const uint32_t k = k0 + lane;
+                                const int32_t id = k < e ? p.ids[k] : -1;
+                                const bool ok = k < e && id >= p.row_begin && id < p.row_end &&
+                                                !self_excluded(id, qid, p.exclude_self);
+                                const unsigned long long m = __ballot(ok);
+                                if (m == 0) continue;
+                                uint32_t at0 = 0;
+                                if (lane == 0) at0 = atomicAdd(&s_seed, (uint32_t)__popcll(m));
+                                at0 = __shfl(at0, 0);
+                                if (at0 >= (uint32_t)p.seed_cap) break;
+                                const uint32_t at = at0 + __popcll(m & ((1ull << lane) - 1ull));
+                                if (ok && at < (uint32_t)p.seed_cap) p.seed_cand[q * p.seed_cap + at] = id;
+                            }
+                        }
                     } else {
                         unsigned long long mask = __ballot(leaf != NO_LEAF);
                         while (mask) {
@@ -360,7 +392,7 @@ __global__ __launch_bounds__(1024) void k_probe(ProbeParams p)
                 }
             }
         }
-        if (MODE == 0) break;
+        if (MODE != 1) break;
         __syncthreads();
 
         // emit set bits in ascending order: each wave owns a contiguous block of words
@@ -411,8 +443,11 @@ __global__ __launch_bounds__(1024) void k_probe(ProbeParams p)
             p.raw[q] = r;
             p.bound[q] = (int64_t)(r < (unsigned long long)range ? r : (unsigned long long)range);
         }
-    } else {
+    } else if (MODE == 1) {
         if (tid == 0) p.cnt[q] = (int32_t)s_emitted;
+    } else {
+        __syncthreads();
+        if (tid == 0) p.seed_cnt[q] = s_seed < (uint32_t)p.seed_cap ? (int32_t)s_seed : p.seed_cap;
     }
 }
 
@@ -421,6 +456,8 @@ void launch_probe(int mode, const ProbeParams &p, int64_t nq, hipStream_t stream
     if (nq <= 0) return;
     if (mode == 0) {
         hipLaunchKernelGGL((k_probe<0>), dim3((unsigned)nq), dim3(256), 0, stream, p);
+    } else if (mode == 2) {
+        hipLaunchKernelGGL((k_probe<2>), dim3((unsigned)nq), dim3(256), 0, stream, p);
     } else {
         size_t shmem = (size_t)p.chunk_words * sizeof(uint32_t);
         hipLaunchKernelGGL((k_probe<1>), dim3((unsigned)nq), dim3(1024), shmem, stream, p);
@@ -508,6 +545,8 @@ __device__ inline void topk_insert(double s, int32_t id, double &ls, int32_t &li
     const bool shift = (lane < K) && better<METRIC>(s, id, ls, lid);
     const unsigned long long mask = __ballot(shift);
     if (mask == 0) return;
+    // the same id reached through two buckets scores identically: keep one (Set semantics)
+    if (__ballot((lane < K) && lid == id && ls == s)) return;
     const int pos = __ffsll((long long)mask) - 1;
     const double ps = __shfl_up(ls, 1);
     const int32_t pid = __shfl_up(lid, 1);
@@ -580,8 +619,9 @@ __global__ __launch_bounds__(256) void k_rerank(RerankParams p)
     int32_t lid = 0x7fffffff;
     double thr_s = ls; int32_t thr_id = lid;
 
-    const int64_t coff = p.cand_off[q];
-    const int32_t cnt = p.cnt ? p.cnt[q] : (int32_t)(p.cand_off[q + 1] - coff);
+    const int64_t coff = p.cand_off ? p.cand_off[q] : q * p.cand_stride;
+    int32_t cnt = p.cnt ? p.cnt[q] : (int32_t)(p.cand_off[q + 1] - coff);
+    if (!p.cand_off && cnt > p.cand_stride) cnt = (int32_t)p.cand_stride;
     const int32_t *cand = p.cand + coff;
     const char *base = (const char *)p.base;
 
@@ -678,6 +718,152 @@ void launch_rerank(int dtype, int metric, const RerankParams &p, int64_t nq, hip
         if (metric == 0) launch_rerank_tm<double, 0>(p, nq, stream);
         else launch_rerank_tm<double, 1>(p, nq, stream);
     }
+}
+
+// ---------------------------------------------------------------------------
+// k_leafscan: bucket-major candidate filter
+// ---------------------------------------------------------------------------
+// The per-query gather above reads a bucket's rows once per query that probes
+// the bucket.  In a batch many queries probe the same buckets, so this kernel
+// turns the loop around: one wave owns a 64-row tile of one bucket (lane = row,
+// the row's dim floats live in registers), and walks the list of queries that
+// reach the bucket; each query row is a wave-uniform broadcast read.  The rows
+// come from HBM once per tile instead of once per (query, bucket).
+//
+// The score here is fp32 and only FILTERS: a row is forwarded to the exact fp64
+// rerank when its fp32 score is within the proven rounding bound of the
+// query's threshold, the exact k-th best score of a seed sample of the query's
+// own candidates (any subset's k-th best bounds the full set's k-th best).
+// Every true top-k member therefore survives; the exact kernel orders them.
+template <int NC, int METRIC>
+__global__ __launch_bounds__(256) void k_leafscan(LeafScanParams p)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= p.ntiles) return;
+    const uint32_t leaf = p.tile_leaf[tile];
+    const int64_t lqb = p.lq_off[leaf], lqe = p.lq_off[leaf + 1];
+    if (lqb == lqe) return;
+    const uint32_t beg = p.leaf_off[leaf] + p.tile_row0[tile];
+    const uint32_t end = p.leaf_off[leaf + 1];
+    const int32_t id = (beg + lane < end) ? p.ids[beg + lane] : -1;
+    const bool valid = id >= p.row_begin && id < p.row_end;
+    float4 x[NC];
+    {
+        const float4 *row = (const float4 *)(p.base + (size_t)(valid ? id - p.row_begin : 0) * p.base_stride);
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            if (valid) x[c] = row[c];
+            else x[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int64_t qi = lqb; qi < lqe; qi++) {
+        const int32_t q = __builtin_amdgcn_readfirstlane(p.leaf_queries[qi]);
+        const float4 *qp = (const float4 *)(p.Q + (size_t)q * p.q_stride);
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            const float4 qv = qp[c];
+            if (METRIC == 1) {
+                const float d0 = qv.x - x[c].x, d1 = qv.y - x[c].y, d2 = qv.z - x[c].z, d3 = qv.w - x[c].w;
+                a0 = fmaf(d0, d0, a0); a1 = fmaf(d1, d1, a1); a2 = fmaf(d2, d2, a2); a3 = fmaf(d3, d3, a3);
+            } else {
+                a0 = fmaf(qv.x, x[c].x, a0); a1 = fmaf(qv.y, x[c].y, a1);
+                a2 = fmaf(qv.z, x[c].z, a2); a3 = fmaf(qv.w, x[c].w, a3);
+            }
+        }
+        const float score = (a0 + a1) + (a2 + a3);
+        const int32_t kth_id = p.seed_ids[(size_t)q * p.k + p.k - 1];
+        const double kth = p.seed_scores[(size_t)q * p.k + p.k - 1];
+        bool pass;
+        if (METRIC == 1) {
+            // exact d <= kth and |score - d| <= delta * d  =>  score <= kth * (1 + delta)
+            const float thr = kth_id < 0 ? HUGE_VALF : (float)(kth * (1.0 + (double)p.delta)) * (1.0f + 1e-6f);
+            pass = score <= thr;
+        } else {
+            // |score - dot| <= delta * |q| * |x| <= delta * |q| * maxnorm
+            const float slack = p.delta * p.qnorm[q] * p.maxnorm * 1.0001f + 1e-30f;
+            const float thr = kth_id < 0 ? -HUGE_VALF : (float)kth - slack - fabsf((float)kth) * 1e-6f;
+            pass = score >= thr;
+        }
+        const int32_t qid = p.qids ? p.qids[q] : -1;
+        pass = pass && valid && !self_excluded(id, qid, p.exclude_self);
+        const unsigned long long m = __ballot(pass);
+        if (m) {
+            const int first = __ffsll((long long)m) - 1;
+            int base = 0;
+            if (lane == first) base = atomicAdd(&p.emit_cnt[q], (int32_t)__popcll(m));
+            base = __shfl(base, first);
+            const int at = base + __popcll(m & lt);
+            if (pass && at < p.emit_cap) p.emit[(size_t)q * p.emit_cap + at] = id;
+        }
+    }
+}
+
+template <int METRIC>
+static void launch_leafscan_m(int nc, const LeafScanParams &p, hipStream_t stream)
+{
+    dim3 grid((unsigned)((p.ntiles + 3) / 4)), block(256);
+#define DPF_LS(NC) hipLaunchKernelGGL((k_leafscan<NC, METRIC>), grid, block, 0, stream, p)
+    if (nc <= 4) DPF_LS(4);
+    else if (nc <= 8) DPF_LS(8);
+    else if (nc <= 13) DPF_LS(13);
+    else if (nc <= 16) DPF_LS(16);
+    else if (nc <= 20) DPF_LS(20);
+    else if (nc <= 25) DPF_LS(25);
+    else DPF_LS(32);
+#undef DPF_LS
+}
+
+// nc = 16-byte pieces per padded row; rows are read as NC pieces, NC >= nc, so the
+// caller pads base and query rows to leafscan_padded_chunks(nc) pieces.
+int leafscan_padded_chunks(int nc)
+{
+    if (nc <= 4) return 4;
+    if (nc <= 8) return 8;
+    if (nc <= 13) return 13;
+    if (nc <= 16) return 16;
+    if (nc <= 20) return 20;
+    if (nc <= 25) return 25;
+    return nc <= 32 ? 32 : -1;
+}
+
+void launch_leafscan(int metric, int chunks16, const LeafScanParams &p, hipStream_t stream)
+{
+    if (p.ntiles <= 0) return;
+    if (metric == 0) launch_leafscan_m<0>(chunks16, p, stream);
+    else launch_leafscan_m<1>(chunks16, p, stream);
+}
+
+// |q| of every (padded) query row, one wave per query
+__global__ void k_qnorm(const float *__restrict__ Q, int64_t q_stride, int64_t nq, float *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    float s = 0.f;
+    for (int64_t i = lane; i < q_stride; i += 64) { const float v = Q[q * q_stride + i]; s += v * v; }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) out[q] = sqrtf(s) * 1.00001f;
+}
+
+void launch_qnorm(const float *Q, int64_t q_stride, int64_t nq, float *out, hipStream_t stream)
+{
+    if (nq <= 0) return;
+    hipLaunchKernelGGL(k_qnorm, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, stream, Q, q_stride, nq, out);
+}
+
+__global__ void k_overflow_flag(const int32_t *__restrict__ emit_cnt, int64_t nq, int32_t cap, int32_t *flag)
+{
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < nq && emit_cnt[q] > cap) atomicOr(flag, 1);
+}
+
+void launch_overflow_flag(const int32_t *emit_cnt, int64_t nq, int32_t cap, int32_t *flag, hipStream_t stream)
+{
+    if (nq <= 0) return;
+    hipLaunchKernelGGL(k_overflow_flag, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, stream, emit_cnt, nq, cap, flag);
 }
 
 // ---------------------------------------------------------------------------

@@ -293,3 +293,61 @@ def test_full_size_properties():
     assert_same_sets(g2.query_batch(pick[:64], Q[:64], steps=1),
                      orc.query_batch(pick[:64], Q[:64].astype(np.float64), steps=1))
     assert g2.stats()["misflag_events"] == orc.misflag_events
+
+
+@pytest.mark.parametrize("metric", ["l2", "dot"])
+@pytest.mark.parametrize("dim", [100, 50, 128, 24])
+def test_bucket_major_rerank_equals_gather_rerank(metric, dim):
+    # f32 handles rerank bucket-major (fp32 filter + exact fp64 rerank of the survivors); the
+    # per-query gather kernel scores every candidate in fp64.  Same ids, same scores, bit for bit.
+    params, X, Q, pick = make_problem(n=20000, nq=300, dim=dim, bucket_overflow=80, table_num=3, permutation_num=2,
+                                      n_clusters=12)
+    fast = DpfIndex(params, metric=metric)
+    slow = DpfIndex(dict(params, flags=2), metric=metric)          # DPF_FLAG_GATHER_ONLY
+    fast.fit(X)
+    slow.fit(X)
+    qids = pick.astype(np.int32)
+    qids[:5] = [0, 5, 127, 128, -1]
+    for steps in (0, 1, 3):
+        fi, fs = fast.query_topk(qids, Q, steps=steps, k=10)
+        assert fast.stats()["last_path"] == 1
+        si, ss = slow.query_topk(qids, Q, steps=steps, k=10)
+        assert slow.stats()["last_path"] == 0
+        assert np.array_equal(fi, si)
+        assert np.array_equal(fs, ss, equal_nan=True)
+    fi, fs = fast.query_topk(qids, Q, steps=1, k=64)
+    si, ss = slow.query_topk(qids, Q, steps=1, k=64)
+    assert np.array_equal(fi, si) and np.array_equal(fs, ss, equal_nan=True)
+    st = fast.stats()
+    assert st["last_pairs"] > 0 and 0 < st["last_forwarded"] <= st["last_raw_candidates"]
+
+
+def test_bucket_major_overflow_falls_back_to_gather(monkeypatch):
+    params, X, Q, pick = make_problem(n=8000, nq=40, bucket_overflow=60, n_clusters=6)
+    slow = DpfIndex(dict(params, flags=2), metric="l2")
+    slow.fit(X)
+    want = slow.query_topk(pick, Q, steps=1, k=10)
+    monkeypatch.setenv("DPF_EMIT_CAP", "4")      # any query forwarding more than 4 candidates overflows
+    fast = DpfIndex(params, metric="l2")
+    fast.fit(X)
+    got = fast.query_topk(pick, Q, steps=1, k=10)
+    assert fast.stats()["last_path"] == 0
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1], equal_nan=True)
+
+
+def test_bucket_major_with_row_shards():
+    params, X, Q, pick = make_problem(n=9000, nq=50, bucket_overflow=50)
+    full = DpfIndex(dict(params, flags=2), metric="l2")
+    full.fit(X)
+    fo, fi = full.query_batch(pick, Q, steps=1)
+    for lo, hi in ((0, 3000), (3000, 9000)):
+        g = DpfIndex(params, metric="l2", row_begin=lo, row_end=hi)
+        g.fit(X)
+        ids, sc = g.query_topk(pick, Q, steps=1, k=10)
+        assert g.stats()["last_path"] == 1
+        for q in range(50):
+            c = fi[fo[q]:fo[q + 1]]
+            c = c[(c >= lo) & (c < hi)]
+            d2 = ((X[c].astype(np.float64) - Q[q].astype(np.float64)) ** 2).sum(axis=1)
+            order = np.lexsort((c, d2))[:10]
+            assert np.array_equal(ids[q, :len(order)], c[order])
