@@ -72,7 +72,7 @@ struct dpf_index {
     DevBuf ws_hq, ws_hqids, ws_hids, ws_hscores;     // device copies for the host-pointer entry points
     DevBuf ws_stage;                                  // fit staging
     DevBuf ws_lq_cnt, ws_lq_off, ws_lq_cursor, ws_leaf_queries, ws_seed_cand, ws_seed_cnt, ws_seed_ids,
-        ws_seed_scores, ws_emit, ws_emit_cnt, ws_flag, ws_qnorm;
+        ws_seed_scores, ws_emit, ws_emit_cnt, ws_flag, ws_qnorm, ws_tau, ws_slack;
     hipEvent_t ev_scan[2]{};
     unsigned long long *d_short_hash = nullptr;
     int64_t *pinned = nullptr;                        // host-pinned scratch (8 x int64)
@@ -200,7 +200,7 @@ extern "C" void dpf_destroy(dpf_index *ix)
     for (int i = 0; i < 2; i++) if (ix->ev_scan[i]) (void)hipEventDestroy(ix->ev_scan[i]);
     DevBuf *more[] = {&ix->d_tile_leaf, &ix->d_tile_row0, &ix->ws_lq_cnt, &ix->ws_lq_off, &ix->ws_lq_cursor, &ix->ws_leaf_queries,
                       &ix->ws_seed_cand, &ix->ws_seed_cnt, &ix->ws_seed_ids, &ix->ws_seed_scores, &ix->ws_emit, &ix->ws_emit_cnt,
-                      &ix->ws_flag, &ix->ws_qnorm};
+                      &ix->ws_flag, &ix->ws_qnorm, &ix->ws_tau, &ix->ws_slack};
     for (DevBuf *b : more) b->release();
     delete ix;
 }
@@ -556,6 +556,8 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     HIPCHECK(ix, ix->ws_emit_cnt.ensure((size_t)nq * 4));
     HIPCHECK(ix, ix->ws_flag.ensure(16));
     HIPCHECK(ix, ix->ws_qnorm.ensure((size_t)nq * 4));
+    HIPCHECK(ix, ix->ws_tau.ensure((size_t)nq * 4));
+    HIPCHECK(ix, ix->ws_slack.ensure((size_t)nq * 4));
 
     if (ix->profiling) HIPCHECK(ix, hipEventRecord(ix->ev[0], stream));
     launch_hash(ix->cfg.dtype, qpad, qstride, nq, ix->hp, ix->ws_hashes.as<int32_t>(), ix->ws_parts.as<int32_t>(), stream);
@@ -598,10 +600,13 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     lp.row_begin = ix->row_begin; lp.row_end = ix->row_begin + ix->base_rows;
     lp.Q = (const float *)qpad; lp.q_stride = ix->dpad;
     lp.qids = d_qids; lp.exclude_self = ix->cfg.exclude_self;
-    lp.seed_scores = ix->ws_seed_scores.as<double>(); lp.seed_ids = ix->ws_seed_ids.as<int32_t>(); lp.k = k;
+    launch_tau(ix->cfg.metric, ix->ws_seed_scores.as<double>(), ix->ws_seed_ids.as<int32_t>(), k, nq,
+               (float)((double)(ix->dpad + 8) * std::ldexp(1.0, -23)), (float)(ix->maxnorm * 1.0001),
+               ix->ws_qnorm.as<float>(), ix->ws_tau.as<int32_t>(), ix->ws_slack.as<float>(), stream);
+    lp.tau = ix->ws_tau.as<int32_t>();
+    lp.slack = ix->cfg.metric == DPF_METRIC_DOT ? ix->ws_slack.as<float>() : nullptr;
+    lp.k = k;
     lp.delta = (float)((double)(ix->dpad + 8) * std::ldexp(1.0, -23));
-    lp.maxnorm = (float)(ix->maxnorm * 1.0001);
-    lp.qnorm = ix->ws_qnorm.as<float>();
     lp.emit = ix->ws_emit.as<int32_t>(); lp.emit_cnt = ix->ws_emit_cnt.as<int32_t>(); lp.emit_cap = EMIT_CAP;
     HIPCHECK(ix, hipEventRecord(ix->ev_scan[0], stream));
     launch_leafscan(ix->cfg.metric, (int)(ix->dpad / 4), lp, stream);
@@ -839,10 +844,12 @@ extern "C" int dpf_get_stats(dpf_index *ix, dpf_stats *out)
     }
     if (ix->profiling && ix->last_valid) {
         float ms = 0;
+        ix->st.last_ms_dedupe = 0;
         if (hipEventElapsedTime(&ms, ix->ev[0], ix->ev[1]) == hipSuccess) ix->st.last_ms_hash = ms;
         if (hipEventElapsedTime(&ms, ix->ev[1], ix->ev[2]) == hipSuccess) ix->st.last_ms_probe = ms;
-        if (hipEventElapsedTime(&ms, ix->ev[2], ix->ev[3]) == hipSuccess) ix->st.last_ms_dedupe = ms;
+        if (ix->last_path == 0 && hipEventElapsedTime(&ms, ix->ev[2], ix->ev[3]) == hipSuccess) ix->st.last_ms_dedupe = ms;
         if (ix->last_k > 0 && hipEventElapsedTime(&ms, ix->ev[4], ix->ev[5]) == hipSuccess) ix->st.last_ms_rerank = ms;
+        (void)hipGetLastError();      // an unrecorded event is not an error of this call
     }
     *out = ix->st;
     return DPF_OK;

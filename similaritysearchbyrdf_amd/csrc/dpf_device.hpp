@@ -75,12 +75,10 @@ struct LeafScanParams {
     int64_t q_stride;            // floats
     const int32_t *qids;
     int32_t exclude_self;
-    const double *seed_scores;   // [nq][k] exact top-k of the seed sample
-    const int32_t *seed_ids;     // [nq][k]
+    int32_t *tau;                // [nq] filter threshold on the fp32 score, order-preserving int encoding; tightened in flight
+    const float *slack;          // [nq] absolute rounding slack (dot metric) or nullptr
     int32_t k;
-    float delta;                 // relative error bound of the fp32 score
-    float maxnorm;               // largest base-row norm (dot metric slack)
-    const float *qnorm;          // [nq] query norms (dot metric slack)
+    float delta;                 // relative rounding bound of the fp32 score
     int32_t *emit;               // [nq][emit_cap]
     int32_t *emit_cnt;           // [nq] may exceed emit_cap: overflow
     int32_t emit_cap;
@@ -108,6 +106,8 @@ size_t hash_shmem_bytes(const HashParams &p);
 void launch_probe(int mode, const ProbeParams &p, int64_t nq, hipStream_t stream);
 void launch_leafscan(int metric, int chunks16, const LeafScanParams &p, hipStream_t stream);
 int leafscan_padded_chunks(int nc);
+void launch_tau(int metric, const double *seed_scores, const int32_t *seed_ids, int k, int64_t nq, float delta,
+                float maxnorm, const float *qnorm, int32_t *tau, float *slack, hipStream_t stream);
 void launch_qnorm(const float *Q, int64_t q_stride, int64_t nq, float *out, hipStream_t stream);
 void launch_overflow_flag(const int32_t *emit_cnt, int64_t nq, int32_t cap, int32_t *flag, hipStream_t stream);
 void launch_scan_i64(const int64_t *in, int64_t n, int64_t *off, hipStream_t stream);

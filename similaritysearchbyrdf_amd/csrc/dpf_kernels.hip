@@ -22,10 +22,15 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 
 #include "dpf_device.hpp"
 
 #pragma clang fp contract(off)
+
+#ifndef LEAFSCAN_WAVES
+#define LEAFSCAN_WAVES 4
+#endif
 
 namespace dpf {
 
@@ -735,11 +740,24 @@ void launch_rerank(int dtype, int metric, const RerankParams &p, int64_t nq, hip
 // query's threshold, the exact k-th best score of a seed sample of the query's
 // own candidates (any subset's k-th best bounds the full set's k-th best).
 // Every true top-k member therefore survives; the exact kernel orders them.
-template <int NC, int METRIC>
-__global__ __launch_bounds__(256) void k_leafscan(LeafScanParams p)
+// order-preserving float <-> int32 (an involution), so thresholds can be tightened with integer atomics
+__device__ __host__ inline int32_t enc_f32(float f)
 {
-    const int lane = threadIdx.x & 63;
-    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    int32_t b;
+    memcpy(&b, &f, 4);
+    return b >= 0 ? b : (b ^ 0x7fffffff);
+}
+__device__ inline float dec_f32(int32_t b)
+{
+    return __int_as_float(b >= 0 ? b : (b ^ 0x7fffffff));
+}
+
+template <int NC, int METRIC>
+__global__ __launch_bounds__(256, LEAFSCAN_WAVES) void k_leafscan(LeafScanParams p, const float *__restrict__ Qg,
+                                                                  const float *__restrict__ baseg)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
     if (tile >= p.ntiles) return;
     const uint32_t leaf = p.tile_leaf[tile];
     const int64_t lqb = p.lq_off[leaf], lqe = p.lq_off[leaf + 1];
@@ -750,7 +768,7 @@ __global__ __launch_bounds__(256) void k_leafscan(LeafScanParams p)
     const bool valid = id >= p.row_begin && id < p.row_end;
     float4 x[NC];
     {
-        const float4 *row = (const float4 *)(p.base + (size_t)(valid ? id - p.row_begin : 0) * p.base_stride);
+        const float4 *row = (const float4 *)(baseg + (size_t)(valid ? id - p.row_begin : 0) * p.base_stride);
 #pragma unroll
         for (int c = 0; c < NC; c++) {
             if (valid) x[c] = row[c];
@@ -758,54 +776,113 @@ __global__ __launch_bounds__(256) void k_leafscan(LeafScanParams p)
         }
     }
     const unsigned long long lt = (1ull << lane) - 1ull;
-    for (int64_t qi = lqb; qi < lqe; qi++) {
-        const int32_t q = __builtin_amdgcn_readfirstlane(p.leaf_queries[qi]);
-        const float4 *qp = (const float4 *)(p.Q + (size_t)q * p.q_stride);
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int64_t q0 = lqb; q0 < lqe; q0 += 64) {
+        const int cnt = (int)((lqe - q0 < 64) ? lqe - q0 : 64);
+        const int32_t myq = lane < cnt ? p.leaf_queries[q0 + lane] : 0;
+        // per-lane prefetch of (threshold, id, slack) of the query this lane names
+        float mtau = 0.f, mslack = 0.f; int32_t mqid = -1;
+        if (lane < cnt) {
+            mtau = dec_f32(__hip_atomic_load(&p.tau[myq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            mqid = p.qids ? p.qids[myq] : -1;
+            mslack = p.slack ? p.slack[myq] : 0.f;
+        }
+        for (int j = 0; j < cnt; j++) {
+            const int32_t q = __builtin_amdgcn_readlane(myq, j);
+            const float tau = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mtau), j));
+            const int32_t qid = __builtin_amdgcn_readlane(mqid, j);
+            // wave-uniform row: scalar loads, operands straight from SGPRs
+            const float4 *qp = (const float4 *)(Qg + (size_t)q * p.q_stride);
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
-        for (int c = 0; c < NC; c++) {
-            const float4 qv = qp[c];
-            if (METRIC == 1) {
-                const float d0 = qv.x - x[c].x, d1 = qv.y - x[c].y, d2 = qv.z - x[c].z, d3 = qv.w - x[c].w;
-                a0 = fmaf(d0, d0, a0); a1 = fmaf(d1, d1, a1); a2 = fmaf(d2, d2, a2); a3 = fmaf(d3, d3, a3);
-            } else {
-                a0 = fmaf(qv.x, x[c].x, a0); a1 = fmaf(qv.y, x[c].y, a1);
-                a2 = fmaf(qv.z, x[c].z, a2); a3 = fmaf(qv.w, x[c].w, a3);
+            for (int c = 0; c < NC; c++) {
+                const float4 qv = qp[c];
+                if (METRIC == 1) {
+                    const float d0 = qv.x - x[c].x, d1 = qv.y - x[c].y, d2 = qv.z - x[c].z, d3 = qv.w - x[c].w;
+                    a0 = fmaf(d0, d0, a0); a1 = fmaf(d1, d1, a1); a2 = fmaf(d2, d2, a2); a3 = fmaf(d3, d3, a3);
+                } else {
+                    a0 = fmaf(qv.x, x[c].x, a0); a1 = fmaf(qv.y, x[c].y, a1);
+                    a2 = fmaf(qv.z, x[c].z, a2); a3 = fmaf(qv.w, x[c].w, a3);
+                }
+            }
+            const float score = (a0 + a1) + (a2 + a3);
+            bool pass = METRIC == 1 ? (score <= tau) : (score >= tau);
+            pass = pass && valid && !self_excluded(id, qid, p.exclude_self);
+            const unsigned long long m = __ballot(pass);
+            if (m) {
+                const int npass = __popcll(m);
+                if (npass >= p.k) {
+                    // >= k distinct rows of this bucket already beat the threshold: the k-th best of
+                    // them bounds the query's k-th best overall, so the threshold can only tighten
+                    int rank = 0;
+                    unsigned long long mm = m;
+                    while (mm) {
+                        const int src = __ffsll((long long)mm) - 1;
+                        mm &= mm - 1;
+                        const float o = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(score), src));
+                        const bool before = METRIC == 1 ? (o < score) : (o > score);
+                        rank += (before || (o == score && src < lane)) ? 1 : 0;
+                    }
+                    if (pass && rank == p.k - 1) {
+                        if (METRIC == 1) {
+                            // k rows have fp32 score <= t  =>  exact k-th best <= t/(1-delta)
+                            //   =>  every true member scores <= t (1+delta)/(1-delta)
+                            const float thr = score * (1.0f + 2.5f * p.delta) * (1.0f + 1e-6f);
+                            atomicMin(&p.tau[q], enc_f32(thr));
+                        } else {
+                            const float sl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mslack), j));
+                            const float thr = score - 2.5f * sl - fabsf(score) * 1e-6f;
+                            atomicMax(&p.tau[q], enc_f32(thr));
+                        }
+                    }
+                }
+                const int first = __ffsll((long long)m) - 1;
+                int base = 0;
+                if (lane == first) base = atomicAdd(&p.emit_cnt[q], (int32_t)npass);
+                base = __shfl(base, first);
+                const int at = base + __popcll(m & lt);
+                if (pass && at < p.emit_cap) p.emit[(size_t)q * p.emit_cap + at] = id;
             }
         }
-        const float score = (a0 + a1) + (a2 + a3);
-        const int32_t kth_id = p.seed_ids[(size_t)q * p.k + p.k - 1];
-        const double kth = p.seed_scores[(size_t)q * p.k + p.k - 1];
-        bool pass;
-        if (METRIC == 1) {
-            // exact d <= kth and |score - d| <= delta * d  =>  score <= kth * (1 + delta)
-            const float thr = kth_id < 0 ? HUGE_VALF : (float)(kth * (1.0 + (double)p.delta)) * (1.0f + 1e-6f);
-            pass = score <= thr;
-        } else {
-            // |score - dot| <= delta * |q| * |x| <= delta * |q| * maxnorm
-            const float slack = p.delta * p.qnorm[q] * p.maxnorm * 1.0001f + 1e-30f;
-            const float thr = kth_id < 0 ? -HUGE_VALF : (float)kth - slack - fabsf((float)kth) * 1e-6f;
-            pass = score >= thr;
-        }
-        const int32_t qid = p.qids ? p.qids[q] : -1;
-        pass = pass && valid && !self_excluded(id, qid, p.exclude_self);
-        const unsigned long long m = __ballot(pass);
-        if (m) {
-            const int first = __ffsll((long long)m) - 1;
-            int base = 0;
-            if (lane == first) base = atomicAdd(&p.emit_cnt[q], (int32_t)__popcll(m));
-            base = __shfl(base, first);
-            const int at = base + __popcll(m & lt);
-            if (pass && at < p.emit_cap) p.emit[(size_t)q * p.emit_cap + at] = id;
-        }
     }
+}
+
+// Filter thresholds on the fp32 score, from the exact k-th best of each query's seed sample.
+//   l2 : exact d <= kth and |score - d| <= delta * d           =>  score <= kth * (1 + delta)
+//   dot: |score - dot| <= delta * |q| * |x| <= delta*|q|*maxnorm =>  score >= kth - slack
+template <int METRIC>
+__global__ void k_tau(const double *__restrict__ seed_scores, const int32_t *__restrict__ seed_ids, int k,
+                      int64_t nq, float delta, float maxnorm, const float *__restrict__ qnorm, int32_t *__restrict__ tau,
+                      float *__restrict__ slack_out)
+{
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    const int32_t kth_id = seed_ids[q * k + k - 1];
+    const double kth = seed_scores[q * k + k - 1];
+    float t;
+    if (METRIC == 1) {
+        t = kth_id < 0 ? HUGE_VALF : (float)(kth * (1.0 + (double)delta)) * (1.0f + 1e-6f);
+    } else {
+        const float slack = delta * qnorm[q] * maxnorm * 1.0001f + 1e-30f;
+        t = kth_id < 0 ? -HUGE_VALF : (float)kth - slack - fabsf((float)kth) * 1e-6f;
+        slack_out[q] = slack;
+    }
+    tau[q] = enc_f32(t);
+}
+
+void launch_tau(int metric, const double *seed_scores, const int32_t *seed_ids, int k, int64_t nq, float delta,
+                float maxnorm, const float *qnorm, int32_t *tau, float *slack, hipStream_t stream)
+{
+    if (nq <= 0) return;
+    dim3 grid((unsigned)((nq + 255) / 256)), block(256);
+    if (metric == 0) hipLaunchKernelGGL((k_tau<0>), grid, block, 0, stream, seed_scores, seed_ids, k, nq, delta, maxnorm, qnorm, tau, slack);
+    else hipLaunchKernelGGL((k_tau<1>), grid, block, 0, stream, seed_scores, seed_ids, k, nq, delta, maxnorm, qnorm, tau, slack);
 }
 
 template <int METRIC>
 static void launch_leafscan_m(int nc, const LeafScanParams &p, hipStream_t stream)
 {
     dim3 grid((unsigned)((p.ntiles + 3) / 4)), block(256);
-#define DPF_LS(NC) hipLaunchKernelGGL((k_leafscan<NC, METRIC>), grid, block, 0, stream, p)
+#define DPF_LS(NC) hipLaunchKernelGGL((k_leafscan<NC, METRIC>), grid, block, 0, stream, p, p.Q, p.base)
     if (nc <= 4) DPF_LS(4);
     else if (nc <= 8) DPF_LS(8);
     else if (nc <= 13) DPF_LS(13);
