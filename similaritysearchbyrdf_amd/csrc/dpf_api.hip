@@ -574,6 +574,17 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     HIPCHECK(ix, hipMemcpyAsync(ix->pinned, ix->ws_lq_off.as<int64_t>() + nl, 8, hipMemcpyDeviceToHost, stream));
     HIPCHECK(ix, hipStreamSynchronize(stream));
     const int64_t pairs = ix->pinned[0];
+    if (getenv("DPF_DEBUG")) {
+        std::vector<uint32_t> c((size_t)nl);
+        HIPCHECK(ix, hipMemcpy(c.data(), ix->ws_lq_cnt.p, (size_t)nl * 4, hipMemcpyDeviceToHost));
+        std::vector<uint32_t> srt(c);
+        std::sort(srt.begin(), srt.end());
+        size_t touched = 0;
+        for (auto v : c) touched += v > 0;
+        fprintf(stderr, "[dpf] buckets %lld touched %zu pairs %lld queries/bucket: median %u p90 %u p99 %u p999 %u max %u\n",
+                (long long)nl, touched, (long long)pairs, srt[srt.size() / 2], srt[srt.size() * 9 / 10],
+                srt[srt.size() * 99 / 100], srt[srt.size() * 999 / 1000], srt.back());
+    }
     HIPCHECK(ix, ix->ws_leaf_queries.ensure((size_t)std::max<int64_t>(pairs, 1) * 4));
     pp.lq_off = ix->ws_lq_off.as<int64_t>();
     pp.lq_cursor = ix->ws_lq_cursor.as<uint32_t>();
@@ -607,6 +618,7 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     lp.slack = ix->cfg.metric == DPF_METRIC_DOT ? ix->ws_slack.as<float>() : nullptr;
     lp.k = k;
     lp.delta = (float)((double)(ix->dpad + 8) * std::ldexp(1.0, -23));
+    lp.debug = getenv("DPF_LS_DEBUG") ? atoi(getenv("DPF_LS_DEBUG")) : 0;
     lp.emit = ix->ws_emit.as<int32_t>(); lp.emit_cnt = ix->ws_emit_cnt.as<int32_t>(); lp.emit_cap = EMIT_CAP;
     HIPCHECK(ix, hipEventRecord(ix->ev_scan[0], stream));
     launch_leafscan(ix->cfg.metric, (int)(ix->dpad / 4), lp, stream);

@@ -82,6 +82,7 @@ struct LeafScanParams {
     int32_t *emit;               // [nq][emit_cap]
     int32_t *emit_cnt;           // [nq] may exceed emit_cap: overflow
     int32_t emit_cap;
+    int32_t debug;               // ablation switch for measurements (0 in production)
 };
 
 struct RerankParams {

@@ -756,12 +756,23 @@ template <int NC, int METRIC>
 __global__ __launch_bounds__(256, LEAFSCAN_WAVES) void k_leafscan(LeafScanParams p, const float *__restrict__ Qg,
                                                                   const float *__restrict__ baseg)
 {
+    // forwarded (query, id) pairs are parked per wave and appended to the queries' lists 64 at a
+    // time, so the wave waits for one round of returning atomics per 64 pairs, not per pair
+    __shared__ int32_t s_fq[4][128], s_fid[4][128];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
     if (tile >= p.ntiles) return;
     const uint32_t leaf = p.tile_leaf[tile];
     const int64_t lqb = p.lq_off[leaf], lqe = p.lq_off[leaf + 1];
     if (lqb == lqe) return;
+    int nbuf = 0;                                  // wave-uniform fill of the parking buffer
+    auto flush = [&](int n) {
+        if (lane < n) {
+            const int32_t fq = s_fq[wave][lane];
+            const int at = atomicAdd(&p.emit_cnt[fq], 1);
+            if (at < p.emit_cap) p.emit[(size_t)fq * p.emit_cap + at] = s_fid[wave][lane];
+        }
+    };
     const uint32_t beg = p.leaf_off[leaf] + p.tile_row0[tile];
     const uint32_t end = p.leaf_off[leaf + 1];
     const int32_t id = (beg + lane < end) ? p.ids[beg + lane] : -1;
@@ -771,11 +782,18 @@ __global__ __launch_bounds__(256, LEAFSCAN_WAVES) void k_leafscan(LeafScanParams
         const float4 *row = (const float4 *)(baseg + (size_t)(valid ? id - p.row_begin : 0) * p.base_stride);
 #pragma unroll
         for (int c = 0; c < NC; c++) {
-            if (valid) x[c] = row[c];
+            if (valid && p.debug != 2) x[c] = row[c];
             else x[c] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
     const unsigned long long lt = (1ull << lane) - 1ull;
+    if (p.debug == 1) {         // rows only
+        float sacc = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; c++) sacc += x[c].x + x[c].y + x[c].z + x[c].w;
+        if (sacc == 1.2345e-30f) p.emit[0] = 1;
+        return;
+    }
     for (int64_t q0 = lqb; q0 < lqe; q0 += 64) {
         const int cnt = (int)((lqe - q0 < 64) ? lqe - q0 : 64);
         const int32_t myq = lane < cnt ? p.leaf_queries[q0 + lane] : 0;
@@ -835,15 +853,25 @@ __global__ __launch_bounds__(256, LEAFSCAN_WAVES) void k_leafscan(LeafScanParams
                         }
                     }
                 }
-                const int first = __ffsll((long long)m) - 1;
-                int base = 0;
-                if (lane == first) base = atomicAdd(&p.emit_cnt[q], (int32_t)npass);
-                base = __shfl(base, first);
-                const int at = base + __popcll(m & lt);
-                if (pass && at < p.emit_cap) p.emit[(size_t)q * p.emit_cap + at] = id;
+                if (pass) {
+                    const int at = nbuf + __popcll(m & lt);
+                    s_fq[wave][at] = q;
+                    s_fid[wave][at] = id;
+                }
+                nbuf += npass;
+                if (nbuf >= 64) {
+                    flush(64);
+                    // move the tail (< 64 entries) to the front
+                    const int rest = nbuf - 64;
+                    int32_t tq = 0, ti = 0;
+                    if (lane < rest) { tq = s_fq[wave][64 + lane]; ti = s_fid[wave][64 + lane]; }
+                    if (lane < rest) { s_fq[wave][lane] = tq; s_fid[wave][lane] = ti; }
+                    nbuf = rest;
+                }
             }
         }
     }
+    flush(nbuf);
 }
 
 // Filter thresholds on the fp32 score, from the exact k-th best of each query's seed sample.
