@@ -61,6 +61,8 @@ struct dpf_index {
 
     DevBuf d_roots, d_dnodes, d_leaf_off, d_ids;
     DevBuf d_tile_leaf, d_tile_row0;         // 64-row tiles of the buckets (bucket-major scan)
+    DevBuf d_base16, ws_q16;                 // bf16 copies of the resident rows / of the query batch
+    int ks16 = -1;                           // 32-dimension bf16 steps per padded row (-1: no bf16 scan)
     int64_t ntiles = 0, num_leaves = 0;
     double maxnorm = 0.0;                    // largest base-row norm seen by dpf_fit
     bool bucket_major = false;               // the bucket-major rerank applies to this handle
@@ -145,7 +147,7 @@ extern "C" int dpf_create(const dpf_config *cfg, dpf_index **out)
     if (cfg->dtype == DPF_F32 && !(cfg->flags & DPF_FLAG_GATHER_ONLY) && !getenv("DPF_GATHER_ONLY")) {
         // rows padded to a piece count the bucket-major scan is instantiated for
         const int nc = leafscan_padded_chunks((int)(ix->dpad / 4));
-        if (nc > 0) { ix->dpad = (int64_t)nc * 4; ix->bucket_major = true; }
+        if (nc > 0) { ix->dpad = (int64_t)nc * 4; ix->bucket_major = true; ix->ks16 = leafscan_bf16_steps(cfg->dim); }
     }
     if (ix->dpad * (int64_t)ix->elem / 16 > rerank_max_chunks16()) { delete ix; return fail(nullptr, DPF_EINVAL, "dpf_create: dim too large for the rerank kernel"); }
     resolve_rows(ix);
@@ -200,7 +202,7 @@ extern "C" void dpf_destroy(dpf_index *ix)
     for (int i = 0; i < 2; i++) if (ix->ev_scan[i]) (void)hipEventDestroy(ix->ev_scan[i]);
     DevBuf *more[] = {&ix->d_tile_leaf, &ix->d_tile_row0, &ix->ws_lq_cnt, &ix->ws_lq_off, &ix->ws_lq_cursor, &ix->ws_leaf_queries,
                       &ix->ws_seed_cand, &ix->ws_seed_cnt, &ix->ws_seed_ids, &ix->ws_seed_scores, &ix->ws_emit, &ix->ws_emit_cnt,
-                      &ix->ws_flag, &ix->ws_qnorm, &ix->ws_tau, &ix->ws_slack};
+                      &ix->d_base16, &ix->ws_q16, &ix->ws_flag, &ix->ws_qnorm, &ix->ws_tau, &ix->ws_slack};
     for (DevBuf *b : more) b->release();
     delete ix;
 }
@@ -400,6 +402,10 @@ extern "C" int dpf_fit(dpf_index *ix, const void *X, int64_t n)
         }
         HIPCHECK(ix, hipMemcpy(ix->h_hashes.data() + (size_t)g0 * L, ix->ws_hashes.p, (size_t)cnt * L * 4, hipMemcpyDeviceToHost));
         HIPCHECK(ix, hipMemcpy(ix->h_parts.data() + (size_t)g0 * L, ix->ws_parts.p, (size_t)cnt * L * 4, hipMemcpyDeviceToHost));
+    }
+    if (ix->bucket_major && ix->ks16 > 0 && new_rows > 0) {
+        HIPCHECK(ix, ix->d_base16.ensure((size_t)new_rows * ix->ks16 * 32 * 2));
+        launch_rows_to_bf16(ix->d_base.as<float>(), ix->dpad, d, new_rows, ix->d_base16.as<uint16_t>(), ix->ks16 * 32, nullptr);
     }
     HIPCHECK(ix, hipDeviceSynchronize());
     ix->base_rows = new_rows;
@@ -618,6 +624,13 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     lp.slack = ix->cfg.metric == DPF_METRIC_DOT ? ix->ws_slack.as<float>() : nullptr;
     lp.k = k;
     lp.delta = (float)((double)(ix->dpad + 8) * std::ldexp(1.0, -23));
+    { const char *e = getenv("DPF_LEAFSCAN"); lp.engine = (e && !strcmp(e, "valu")) ? 0 : ((e && !strcmp(e, "f32")) || ix->ks16 < 0 ? 1 : 2); }
+    lp.ks = ix->ks16; lp.base16 = ix->d_base16.as<uint16_t>(); lp.Q16 = nullptr;
+    if (lp.engine == 2) {
+        HIPCHECK(ix, ix->ws_q16.ensure((size_t)nq * ix->ks16 * 32 * 2));
+        launch_rows_to_bf16((const float *)qpad, ix->dpad, ix->cfg.dim, nq, ix->ws_q16.as<uint16_t>(), ix->ks16 * 32, stream);
+        lp.Q16 = ix->ws_q16.as<uint16_t>();
+    }
     lp.debug = getenv("DPF_LS_DEBUG") ? atoi(getenv("DPF_LS_DEBUG")) : 0;
     lp.emit = ix->ws_emit.as<int32_t>(); lp.emit_cnt = ix->ws_emit_cnt.as<int32_t>(); lp.emit_cap = EMIT_CAP;
     HIPCHECK(ix, hipEventRecord(ix->ev_scan[0], stream));

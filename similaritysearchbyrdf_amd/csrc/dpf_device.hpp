@@ -83,6 +83,10 @@ struct LeafScanParams {
     int32_t *emit_cnt;           // [nq] may exceed emit_cap: overflow
     int32_t emit_cap;
     int32_t debug;               // ablation switch for measurements (0 in production)
+    int32_t engine;              // 0 = vector ALU (lane per row), 1 = f32 MFMA 16x16x4, 2 = bf16 MFMA 16x16x32
+    const uint16_t *Q16;         // bf16 copies (engine 2): queries [nq][ks*32], rows [rows][ks*32]
+    const uint16_t *base16;
+    int32_t ks;
 };
 
 struct RerankParams {
@@ -107,6 +111,9 @@ size_t hash_shmem_bytes(const HashParams &p);
 void launch_probe(int mode, const ProbeParams &p, int64_t nq, hipStream_t stream);
 void launch_leafscan(int metric, int chunks16, const LeafScanParams &p, hipStream_t stream);
 int leafscan_padded_chunks(int nc);
+int leafscan_bf16_steps(int dim);
+void launch_rows_to_bf16(const float *src, int64_t src_stride, int dim, int64_t n, uint16_t *dst, int dst_stride,
+                         hipStream_t stream);
 void launch_tau(int metric, const double *seed_scores, const int32_t *seed_ids, int k, int64_t nq, float delta,
                 float maxnorm, const float *qnorm, int32_t *tau, float *slack, hipStream_t stream);
 void launch_qnorm(const float *Q, int64_t q_stride, int64_t nq, float *out, hipStream_t stream);

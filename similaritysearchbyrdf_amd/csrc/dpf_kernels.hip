@@ -20,6 +20,7 @@
 // multiply-add is wanted (rerank) it is written as fma().
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -874,6 +875,396 @@ __global__ __launch_bounds__(256, LEAFSCAN_WAVES) void k_leafscan(LeafScanParams
     flush(nbuf);
 }
 
+// ---------------------------------------------------------------------------
+// k_leafscan_mfma: the same bucket-major filter on the matrix cores
+// ---------------------------------------------------------------------------
+// A wave owns a 64-row tile (four 16-row blocks) of one bucket and walks the
+// bucket's queries 16 at a time: scores[16 queries][16 rows] = Q . X^T is a
+// chain of v_mfma_f32_16x16x4_f32.  Neither operand is broadcast: lane
+// (i = lane & 15, g = lane >> 4) holds the 16-byte pieces g, g+4, g+8, ... of
+// vector i, for the query block (A operand) and for each row block (B operand)
+// alike, so MFMA step s multiplies the same dimensions on both sides.  The
+// accumulator leaves lane l with the dot products of row (l & 15) against the
+// queries 4*(l >> 4) + {0..3}.  Squared distances come from
+// |q|^2 + |x|^2 - 2 q.x; the cancellation this form adds is covered by an
+// absolute slack proportional to |q|^2 + |x|^2, so the filter stays
+// conservative and the exact fp64 rerank still decides the result.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int NP, int METRIC>
+__global__ __launch_bounds__(256, 2) void k_leafscan_mfma(LeafScanParams p, const float *__restrict__ Qg,
+                                                          const float *__restrict__ baseg)
+{
+    __shared__ int32_t s_fq[4][128], s_fid[4][128];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+    if (tile >= p.ntiles) return;
+    const uint32_t leaf = p.tile_leaf[tile];
+    const int64_t lqb = p.lq_off[leaf], lqe = p.lq_off[leaf + 1];
+    if (lqb == lqe) return;
+    const int i16 = lane & 15, g = lane >> 4;
+    const int nc = (int)(p.base_stride / 4);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const unsigned long long gmask = 0xffffull << (16 * g);
+    // absolute rounding slack of |q|^2 + |x|^2 - 2 q.x in fp32, per unit of (|q|^2 + |x|^2)
+    const float cslack = 3.0f * p.delta;
+
+    int nbuf = 0;
+    auto flush = [&](int n) {
+        if (lane < n) {
+            const int32_t fq = s_fq[wave][lane];
+            const int at = atomicAdd(&p.emit_cnt[fq], 1);
+            if (at < p.emit_cap) p.emit[(size_t)fq * p.emit_cap + at] = s_fid[wave][lane];
+        }
+    };
+
+    const uint32_t beg = p.leaf_off[leaf] + p.tile_row0[tile];
+    const uint32_t end = p.leaf_off[leaf + 1];
+    float4 xb[4][NP];
+    int32_t idj[4];
+    float xn[4];
+#pragma unroll
+    for (int rb = 0; rb < 4; rb++) {
+        const uint32_t idx = beg + rb * 16 + i16;
+        int32_t id = idx < end ? p.ids[idx] : -1;
+        if (!(id >= p.row_begin && id < p.row_end)) id = -1;
+        idj[rb] = id;
+        const float4 *row = (const float4 *)(baseg + (size_t)(id >= 0 ? id - p.row_begin : 0) * p.base_stride);
+        float s = 0.f;
+#pragma unroll
+        for (int t = 0; t < NP; t++) {
+            const int c = g + 4 * t;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (id >= 0 && c < nc) v = row[c];
+            xb[rb][t] = v;
+            s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        }
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        xn[rb] = s;
+    }
+
+    for (int64_t q0 = lqb; q0 < lqe; q0 += 16) {
+        const int32_t qs = (q0 + i16 < lqe) ? p.leaf_queries[q0 + i16] : -1;
+        float4 qa[NP];
+        float qn_slot = 0.f;
+        {
+            const float4 *qrow = (const float4 *)(Qg + (size_t)(qs >= 0 ? qs : 0) * p.q_stride);
+#pragma unroll
+            for (int t = 0; t < NP; t++) {
+                const int c = g + 4 * t;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (qs >= 0 && c < nc) v = qrow[c];
+                qa[t] = v;
+                qn_slot += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+            }
+            qn_slot += __shfl_xor(qn_slot, 16);
+            qn_slot += __shfl_xor(qn_slot, 32);
+        }
+        // an empty slot never passes
+        float tau_slot = METRIC == 1 ? -HUGE_VALF : HUGE_VALF;
+        int32_t qid_slot = -1;
+        if (qs >= 0) {
+            tau_slot = dec_f32(__hip_atomic_load(&p.tau[qs], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            qid_slot = p.qids ? p.qids[qs] : -1;
+        }
+        f32x4 acc[4];
+#pragma unroll
+        for (int rb = 0; rb < 4; rb++) acc[rb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < NP; t++) {
+            const float av[4] = {qa[t].x, qa[t].y, qa[t].z, qa[t].w};
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+#pragma unroll
+                for (int rb = 0; rb < 4; rb++) {
+                    const float bv = e == 0 ? xb[rb][t].x : (e == 1 ? xb[rb][t].y : (e == 2 ? xb[rb][t].z : xb[rb][t].w));
+                    acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv, acc[rb], 0, 0, 0);
+                }
+            }
+        }
+        // lane l now holds q(4g + r) . x(rb*16 + i16) in acc[rb][r]
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int slot = 4 * g + r;
+            const float tq = __shfl(tau_slot, slot);
+            const float qnq = __shfl(qn_slot, slot);
+            const int32_t qq = __shfl(qs, slot);
+            const int32_t qidq = __shfl(qid_slot, slot);
+            int tight = 0;
+#pragma unroll
+            for (int rb = 0; rb < 4; rb++) {
+                const float dotv = acc[rb][r];
+                float score, thr;
+                if (METRIC == 1) {
+                    score = (qnq + xn[rb]) - 2.0f * dotv;
+                    thr = tq + cslack * (qnq + xn[rb]);
+                } else {
+                    score = dotv;
+                    thr = tq;
+                }
+                const bool ok = idj[rb] >= 0 && qq >= 0 && !self_excluded(idj[rb], qidq, p.exclude_self);
+                const bool pass = ok && (METRIC == 1 ? (score <= thr) : (score >= thr));
+                if (METRIC == 1) {
+                    // rows whose EXACT distance is provably below 0.85 * threshold
+                    const bool deep = ok && (score + cslack * (qnq + xn[rb]) <= 0.85f * tq);
+                    tight += __popcll(__ballot(deep) & gmask);
+                }
+                const unsigned long long m = __ballot(pass);
+                if (m) {
+                    if (pass) {
+                        const int at = nbuf + __popcll(m & lt);
+                        s_fq[wave][at] = qq;
+                        s_fid[wave][at] = idj[rb];
+                    }
+                    nbuf += __popcll(m);
+                    if (nbuf >= 64) {
+                        flush(64);
+                        const int rest = nbuf - 64;
+                        int32_t tq2 = 0, ti2 = 0;
+                        if (lane < rest) { tq2 = s_fq[wave][64 + lane]; ti2 = s_fid[wave][64 + lane]; }
+                        if (lane < rest) { s_fq[wave][lane] = tq2; s_fid[wave][lane] = ti2; }
+                        nbuf = rest;
+                    }
+                }
+            }
+            if (METRIC == 1 && tight >= p.k && i16 == 0 && qq >= 0) {
+                // >= k distinct rows of this bucket are exactly closer than 0.85 * threshold: the
+                // query's k-th best is too, so 0.85 * threshold (plus rounding room) is a valid filter
+                const float thr = 0.85f * tq * (1.0f + p.delta) * (1.0f + 1e-6f);
+                atomicMin(&p.tau[qq], enc_f32(thr));
+            }
+        }
+    }
+    flush(nbuf);
+}
+
+template <int METRIC>
+static void launch_leafscan_mfma_m(int nc, const LeafScanParams &p, hipStream_t stream)
+{
+    dim3 grid((unsigned)((p.ntiles + 3) / 4)), block(256);
+#define DPF_LM(NP) hipLaunchKernelGGL((k_leafscan_mfma<NP, METRIC>), grid, block, 0, stream, p, p.Q, p.base)
+    if (nc <= 8) DPF_LM(2);
+    else if (nc <= 16) DPF_LM(4);
+    else if (nc <= 28) DPF_LM(7);
+    else DPF_LM(8);
+#undef DPF_LM
+}
+
+// ---------------------------------------------------------------------------
+// k_leafscan_bf16: the bucket-major filter on a bf16 copy of the rows
+// ---------------------------------------------------------------------------
+// Same tiling as k_leafscan_mfma, but both operands are bf16 (rows padded to
+// KS*32 dimensions, 64*KS bytes, never straddling a 128-byte line) and the
+// products run on v_mfma_f32_16x16x32_bf16: half the HBM bytes per row and 1/7
+// of the matrix-core cycles.  The filter stays exact-safe because the
+// quantisation is bounded: |x~ - x| <= 2^-9 |x| for round-to-nearest bf16, so
+// | |q~ - x~| - |q - x| | <= 2^-9 (|q| + |x|) =: eta, and a candidate is
+// forwarded whenever its bf16 distance could still be within the threshold,
+//     s - slack32 <= (sqrt(tau) + eta)^2 .
+// What is forwarded is rescored in fp64 from the fp32 rows.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ inline float bf16_sumsq(const bf16x8 &v)
+{
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; e++) { const float f = (float)v[e]; s = fmaf(f, f, s); }
+    return s;
+}
+
+template <int KS, int METRIC>
+__global__ __launch_bounds__(256, 4) void k_leafscan_bf16(LeafScanParams p, const uint16_t *__restrict__ Q16,
+                                                          const uint16_t *__restrict__ B16)
+{
+    __shared__ int32_t s_fq[4][128], s_fid[4][128];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+    if (tile >= p.ntiles) return;
+    const uint32_t leaf = p.tile_leaf[tile];
+    const int64_t lqb = p.lq_off[leaf], lqe = p.lq_off[leaf + 1];
+    if (lqb == lqe) return;
+    const int i16 = lane & 15, g = lane >> 4;
+    constexpr int STRIDE = KS * 32;                       // bf16 elements per padded row
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const unsigned long long gmask = 0xffffull << (16 * g);
+    const float c32 = 3.0f * (float)(STRIDE + 8) * 5.9604645e-8f;    // fp32 accumulation, per unit of |q|^2+|x|^2
+    const float cq = 0.001953125f * 1.002f;                          // 2^-9 with room for the rounded norms
+
+    int nbuf = 0;
+    auto flush = [&](int n) {
+        if (lane < n) {
+            const int32_t fq = s_fq[wave][lane];
+            const int at = atomicAdd(&p.emit_cnt[fq], 1);
+            if (at < p.emit_cap) p.emit[(size_t)fq * p.emit_cap + at] = s_fid[wave][lane];
+        }
+    };
+
+    const uint32_t beg = p.leaf_off[leaf] + p.tile_row0[tile];
+    const uint32_t end = p.leaf_off[leaf + 1];
+    bf16x8 xb[4][KS];
+    int32_t idj[4];
+    float xn[4], xr[4];                                   // |x~|^2 and an upper bound of |x|
+#pragma unroll
+    for (int rb = 0; rb < 4; rb++) {
+        const uint32_t idx = beg + rb * 16 + i16;
+        int32_t id = idx < end ? p.ids[idx] : -1;
+        if (!(id >= p.row_begin && id < p.row_end)) id = -1;
+        idj[rb] = id;
+        const uint16_t *row = B16 + (size_t)(id >= 0 ? id - p.row_begin : 0) * STRIDE + 8 * g;
+        float s = 0.f;
+#pragma unroll
+        for (int t = 0; t < KS; t++) {
+            xb[rb][t] = *(const bf16x8 *)(row + 32 * t);
+            s += bf16_sumsq(xb[rb][t]);
+        }
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        xn[rb] = s;
+        xr[rb] = sqrtf(s) * 1.004f;
+    }
+
+    for (int64_t q0 = lqb; q0 < lqe; q0 += 16) {
+        const int32_t qs = (q0 + i16 < lqe) ? p.leaf_queries[q0 + i16] : -1;
+        bf16x8 qa[KS];
+        float qn_slot = 0.f;
+        {
+            const uint16_t *qrow = Q16 + (size_t)(qs >= 0 ? qs : 0) * STRIDE + 8 * g;
+#pragma unroll
+            for (int t = 0; t < KS; t++) {
+                qa[t] = *(const bf16x8 *)(qrow + 32 * t);
+                qn_slot += bf16_sumsq(qa[t]);
+            }
+            qn_slot += __shfl_xor(qn_slot, 16);
+            qn_slot += __shfl_xor(qn_slot, 32);
+        }
+        float tau_slot = METRIC == 1 ? -1.0f : HUGE_VALF;  // an empty slot never passes
+        int32_t qid_slot = -1;
+        if (qs >= 0) {
+            tau_slot = dec_f32(__hip_atomic_load(&p.tau[qs], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            qid_slot = p.qids ? p.qids[qs] : -1;
+        }
+        f32x4 acc[4];
+#pragma unroll
+        for (int rb = 0; rb < 4; rb++) acc[rb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < KS; t++)
+#pragma unroll
+            for (int rb = 0; rb < 4; rb++) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[t], xb[rb][t], acc[rb], 0, 0, 0);
+        // lane l holds q~(4g + r) . x~(rb*16 + i16) in acc[rb][r]
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int slot = 4 * g + r;
+            const float tq = __shfl(tau_slot, slot);
+            const float qnq = __shfl(qn_slot, slot);
+            const int32_t qq = __shfl(qs, slot);
+            const int32_t qidq = __shfl(qid_slot, slot);
+            const float qr = sqrtf(qnq) * 1.004f;            // upper bound of |q|
+            const float st = METRIC == 1 ? sqrtf(fmaxf(tq, 0.f)) : 0.f;
+            const float sdeep = METRIC == 1 ? sqrtf(fmaxf(0.85f * tq, 0.f)) : 0.f;
+            int tight = 0;
+#pragma unroll
+            for (int rb = 0; rb < 4; rb++) {
+                const float dotv = acc[rb][r];
+                const bool ok = idj[rb] >= 0 && qq >= 0 && tq >= (METRIC == 1 ? 0.f : -HUGE_VALF) &&
+                                !self_excluded(idj[rb], qidq, p.exclude_self);
+                bool pass, deep;
+                if (METRIC == 1) {
+                    const float s = (qnq + xn[rb]) - 2.0f * dotv;
+                    const float slack32 = c32 * (qnq + xn[rb]);
+                    const float eta = cq * (qr + xr[rb]);
+                    const float hi = st + eta;
+                    pass = (s - slack32) <= hi * hi * 1.000001f;
+                    // exact sqrt(d) <= sqrt(s + slack32) + eta; provably below sqrt(0.85 tau)?
+                    const float lo = sdeep - eta;
+                    deep = lo > 0.f && (s + slack32) <= lo * lo * 0.999999f;
+                } else {
+                    const float slack = (0.00390625f * 1.01f + c32) * qr * xr[rb] + 1e-30f;
+                    pass = dotv + slack >= tq;
+                    deep = false;
+                }
+                pass = pass && ok;
+                if (METRIC == 1) tight += __popcll(__ballot(deep && ok) & gmask);
+                const unsigned long long m = __ballot(pass);
+                if (m) {
+                    if (pass) {
+                        const int at = nbuf + __popcll(m & lt);
+                        s_fq[wave][at] = qq;
+                        s_fid[wave][at] = idj[rb];
+                    }
+                    nbuf += __popcll(m);
+                    if (nbuf >= 64) {
+                        flush(64);
+                        const int rest = nbuf - 64;
+                        int32_t tq2 = 0, ti2 = 0;
+                        if (lane < rest) { tq2 = s_fq[wave][64 + lane]; ti2 = s_fid[wave][64 + lane]; }
+                        if (lane < rest) { s_fq[wave][lane] = tq2; s_fid[wave][lane] = ti2; }
+                        nbuf = rest;
+                    }
+                }
+            }
+            if (METRIC == 1 && tight >= p.k && i16 == 0 && qq >= 0) {
+                // >= k distinct rows of this bucket are provably closer than 0.85 * threshold, so the
+                // query's k-th best is too
+                const float thr = 0.85f * tq * (1.0f + 1e-6f);
+                atomicMin(&p.tau[qq], enc_f32(thr));
+            }
+        }
+    }
+    flush(nbuf);
+}
+
+template <int METRIC>
+static void launch_leafscan_bf16_m(const LeafScanParams &p, hipStream_t stream)
+{
+    dim3 grid((unsigned)((p.ntiles + 3) / 4)), block(256);
+#define DPF_LB(KS) hipLaunchKernelGGL((k_leafscan_bf16<KS, METRIC>), grid, block, 0, stream, p, p.Q16, p.base16)
+    switch (p.ks) {
+    case 1: DPF_LB(1); break;
+    case 2: DPF_LB(2); break;
+    case 4: DPF_LB(4); break;
+    default: DPF_LB(8); break;
+    }
+#undef DPF_LB
+}
+
+// bf16 steps (of 32 dimensions) a padded row takes: 1, 2, 4 or 8; -1 when the row is too long
+int leafscan_bf16_steps(int dim)
+{
+    const int ks = (dim + 31) / 32;
+    if (ks <= 1) return 1;
+    if (ks <= 2) return 2;
+    if (ks <= 4) return 4;
+    return ks <= 8 ? 8 : -1;
+}
+
+// fp32 rows (stride src_stride floats, `dim` meaningful) -> bf16 rows of dst_stride elements,
+// round to nearest even, zero padded
+__global__ void k_rows_to_bf16(const float *__restrict__ src, int64_t src_stride, int dim, int64_t n,
+                               uint16_t *__restrict__ dst, int dst_stride)
+{
+    const int64_t total = n * dst_stride;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / dst_stride;
+        const int c = (int)(i - r * dst_stride);
+        uint16_t o = 0;
+        if (c < dim) {
+            const uint32_t u = __float_as_uint(src[r * src_stride + c]);
+            o = (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+        }
+        dst[i] = o;
+    }
+}
+
+void launch_rows_to_bf16(const float *src, int64_t src_stride, int dim, int64_t n, uint16_t *dst, int dst_stride,
+                         hipStream_t stream)
+{
+    if (n <= 0) return;
+    const int64_t total = n * dst_stride;
+    unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 65535 * 8);
+    hipLaunchKernelGGL(k_rows_to_bf16, dim3(grid), dim3(256), 0, stream, src, src_stride, dim, n, dst, dst_stride);
+}
+
 // Filter thresholds on the fp32 score, from the exact k-th best of each query's seed sample.
 //   l2 : exact d <= kth and |score - d| <= delta * d           =>  score <= kth * (1 + delta)
 //   dot: |score - dot| <= delta * |q| * |x| <= delta*|q|*maxnorm =>  score >= kth - slack
@@ -937,6 +1328,16 @@ int leafscan_padded_chunks(int nc)
 void launch_leafscan(int metric, int chunks16, const LeafScanParams &p, hipStream_t stream)
 {
     if (p.ntiles <= 0) return;
+    if (p.engine == 2) {
+        if (metric == 0) launch_leafscan_bf16_m<0>(p, stream);
+        else launch_leafscan_bf16_m<1>(p, stream);
+        return;
+    }
+    if (p.engine == 1) {
+        if (metric == 0) launch_leafscan_mfma_m<0>(chunks16, p, stream);
+        else launch_leafscan_mfma_m<1>(chunks16, p, stream);
+        return;
+    }
     if (metric == 0) launch_leafscan_m<0>(chunks16, p, stream);
     else launch_leafscan_m<1>(chunks16, p, stream);
 }
