@@ -60,6 +60,7 @@ struct dpf_index {
     int64_t base_rows = 0;                   // resident rows: ids row_begin .. row_begin+base_rows-1
 
     DevBuf d_roots, d_dnodes, d_leaf_off, d_ids;
+    DevBuf d_tiles;                          // {bucket, first id slot, rows, 0} per tile
     DevBuf d_tile_leaf, d_tile_row0;         // 64-row tiles of the buckets (bucket-major scan)
     DevBuf d_base16, ws_q16;                 // bf16 copies of the resident rows / of the query batch
     int ks16 = -1;                           // 32-dimension bf16 steps per padded row (-1: no bf16 scan)
@@ -200,7 +201,7 @@ extern "C" void dpf_destroy(dpf_index *ix)
     if (ix->pinned) (void)hipHostFree(ix->pinned);
     for (int i = 0; i < 6; i++) if (ix->ev[i]) (void)hipEventDestroy(ix->ev[i]);
     for (int i = 0; i < 2; i++) if (ix->ev_scan[i]) (void)hipEventDestroy(ix->ev_scan[i]);
-    DevBuf *more[] = {&ix->d_tile_leaf, &ix->d_tile_row0, &ix->ws_lq_cnt, &ix->ws_lq_off, &ix->ws_lq_cursor, &ix->ws_leaf_queries,
+    DevBuf *more[] = {&ix->d_tiles, &ix->d_tile_leaf, &ix->d_tile_row0, &ix->ws_lq_cnt, &ix->ws_lq_off, &ix->ws_lq_cursor, &ix->ws_leaf_queries,
                       &ix->ws_seed_cand, &ix->ws_seed_cnt, &ix->ws_seed_ids, &ix->ws_seed_scores, &ix->ws_emit, &ix->ws_emit_cnt,
                       &ix->d_base16, &ix->ws_q16, &ix->ws_flag, &ix->ws_qnorm, &ix->ws_tau, &ix->ws_slack};
     for (DevBuf *b : more) b->release();
@@ -321,9 +322,16 @@ static int upload_snapshot(dpf_index *ix, ForestSnapshot &s)
         s.ids.swap(ids);
         s.leaf_off.swap(off);
     }
-    std::vector<uint32_t> tile_leaf, tile_row0;
-    for (size_t l = 0; l + 1 < s.leaf_off.size(); l++)
-        for (uint32_t r = 0; r < s.leaf_off[l + 1] - s.leaf_off[l]; r += 64) { tile_leaf.push_back((uint32_t)l); tile_row0.push_back(r); }
+    std::vector<uint32_t> tile_leaf, tile_row0, tiles;
+    for (size_t l = 0; l + 1 < s.leaf_off.size(); l++) {
+        const uint32_t len = s.leaf_off[l + 1] - s.leaf_off[l];
+        for (uint32_t r = 0; r < len; r += 64) {
+            tile_leaf.push_back((uint32_t)l);
+            tile_row0.push_back(r);
+            tiles.push_back((uint32_t)l); tiles.push_back(s.leaf_off[l] + r); tiles.push_back(std::min<uint32_t>(64u, len - r)); tiles.push_back(0u);
+        }
+    }
+    if ((rc = upload(ix, ix->d_tiles, tiles)) != DPF_OK) return rc;
     ix->ntiles = (int64_t)tile_leaf.size();
     ix->num_leaves = (int64_t)s.leaf_off.size() - 1;
     if ((rc = upload(ix, ix->d_tile_leaf, tile_leaf)) != DPF_OK) return rc;
@@ -532,7 +540,7 @@ static const int32_t SEED_CAP = 1024;     // seed sample per query (ids from tab
 static int32_t emit_cap_setting()
 {
     const char *e = getenv("DPF_EMIT_CAP");
-    int v = e ? atoi(e) : 2048;
+    int v = e ? atoi(e) : 8192;
     return v < 1 ? 1 : v;
 }
 
@@ -610,6 +618,7 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     if (ix->cfg.metric == DPF_METRIC_DOT) launch_qnorm((const float *)qpad, ix->dpad, nq, ix->ws_qnorm.as<float>(), stream);
 
     LeafScanParams lp;
+    lp.tiles = (const uint4 *)ix->d_tiles.p;
     lp.tile_leaf = ix->d_tile_leaf.as<uint32_t>(); lp.tile_row0 = ix->d_tile_row0.as<uint32_t>(); lp.ntiles = ix->ntiles;
     lp.leaf_off = ix->d_leaf_off.as<uint32_t>(); lp.ids = ix->d_ids.as<int32_t>();
     lp.lq_off = ix->ws_lq_off.as<int64_t>(); lp.leaf_queries = ix->ws_leaf_queries.as<int32_t>();
@@ -640,6 +649,13 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     HIPCHECK(ix, hipMemcpyAsync(ix->pinned + 1, ix->ws_flag.p, 4, hipMemcpyDeviceToHost, stream));
     HIPCHECK(ix, hipStreamSynchronize(stream));
     ix->st.last_pairs = pairs;
+    if (getenv("DPF_DEBUG")) {
+        std::vector<int32_t> c((size_t)nq);
+        HIPCHECK(ix, hipMemcpy(c.data(), ix->ws_emit_cnt.p, (size_t)nq * 4, hipMemcpyDeviceToHost));
+        std::sort(c.begin(), c.end());
+        fprintf(stderr, "[dpf] forwarded per query: median %d p90 %d p99 %d max %d (cap %d)\n", c[c.size() / 2],
+                c[c.size() * 9 / 10], c[c.size() * 99 / 100], c.back(), EMIT_CAP);
+    }
     if ((int32_t)(ix->pinned[1] & 0xffffffff) != 0) return DPF_OK;     // overflow: gather path decides
 
     fill_rerank_params(ix, rp, qpad, k, nullptr, ix->ws_emit_cnt.as<int32_t>(), ix->ws_emit.as<int32_t>(), d_ids, d_scores);

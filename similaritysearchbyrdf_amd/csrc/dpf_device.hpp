@@ -63,6 +63,7 @@ struct ProbeParams {
 struct LeafScanParams {
     const uint32_t *tile_leaf;   // [ntiles] bucket of each 64-row tile
     const uint32_t *tile_row0;   // [ntiles] first row of the tile inside its bucket
+    const uint4 *tiles;          // [ntiles] {bucket, first slot in ids[], rows in the tile, 0}
     int64_t ntiles;
     const uint32_t *leaf_off;
     const int32_t *ids;

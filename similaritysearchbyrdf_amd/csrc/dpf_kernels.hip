@@ -29,6 +29,9 @@
 
 #pragma clang fp contract(off)
 
+#ifndef LS16_WAVES
+#define LS16_WAVES 3
+#endif
 #ifndef LEAFSCAN_WAVES
 #define LEAFSCAN_WAVES 4
 #endif
@@ -1074,14 +1077,15 @@ __device__ inline float bf16_sumsq(const bf16x8 &v)
 }
 
 template <int KS, int METRIC>
-__global__ __launch_bounds__(256, 4) void k_leafscan_bf16(LeafScanParams p, const uint16_t *__restrict__ Q16,
-                                                          const uint16_t *__restrict__ B16)
+__global__ __launch_bounds__(256, LS16_WAVES) void k_leafscan_bf16(LeafScanParams p, const uint16_t *__restrict__ Q16,
+                                                                   const uint16_t *__restrict__ B16)
 {
     __shared__ int32_t s_fq[4][128], s_fid[4][128];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
     if (tile >= p.ntiles) return;
-    const uint32_t leaf = p.tile_leaf[tile];
+    const uint4 td = p.tiles[tile];                      // {bucket, first id slot, rows, -}
+    const uint32_t leaf = td.x;
     const int64_t lqb = p.lq_off[leaf], lqe = p.lq_off[leaf + 1];
     if (lqb == lqe) return;
     const int i16 = lane & 15, g = lane >> 4;
@@ -1100,15 +1104,13 @@ __global__ __launch_bounds__(256, 4) void k_leafscan_bf16(LeafScanParams p, cons
         }
     };
 
-    const uint32_t beg = p.leaf_off[leaf] + p.tile_row0[tile];
-    const uint32_t end = p.leaf_off[leaf + 1];
     bf16x8 xb[4][KS];
     int32_t idj[4];
-    float xn[4], xr[4];                                   // |x~|^2 and an upper bound of |x|
+    float xn[4], cx[4];                                   // |x~|^2 and 2^-9 * (upper bound of |x|)
 #pragma unroll
     for (int rb = 0; rb < 4; rb++) {
-        const uint32_t idx = beg + rb * 16 + i16;
-        int32_t id = idx < end ? p.ids[idx] : -1;
+        const uint32_t idx = rb * 16 + i16;
+        int32_t id = idx < td.z ? p.ids[td.y + idx] : -1;
         if (!(id >= p.row_begin && id < p.row_end)) id = -1;
         idj[rb] = id;
         const uint16_t *row = B16 + (size_t)(id >= 0 ? id - p.row_begin : 0) * STRIDE + 8 * g;
@@ -1121,11 +1123,13 @@ __global__ __launch_bounds__(256, 4) void k_leafscan_bf16(LeafScanParams p, cons
         s += __shfl_xor(s, 16);
         s += __shfl_xor(s, 32);
         xn[rb] = s;
-        xr[rb] = sqrtf(s) * 1.004f;
+        cx[rb] = cq * sqrtf(s) * 1.004f;
     }
 
+    int32_t qs_next = (lqb + i16 < lqe) ? p.leaf_queries[lqb + i16] : -1;
     for (int64_t q0 = lqb; q0 < lqe; q0 += 16) {
-        const int32_t qs = (q0 + i16 < lqe) ? p.leaf_queries[q0 + i16] : -1;
+        const int32_t qs = qs_next;
+        if (q0 + 16 < lqe) qs_next = (q0 + 16 + i16 < lqe) ? p.leaf_queries[q0 + 16 + i16] : -1;
         bf16x8 qa[KS];
         float qn_slot = 0.f;
         {
@@ -1138,12 +1142,19 @@ __global__ __launch_bounds__(256, 4) void k_leafscan_bf16(LeafScanParams p, cons
             qn_slot += __shfl_xor(qn_slot, 16);
             qn_slot += __shfl_xor(qn_slot, 32);
         }
+        // per-slot constants, computed once by the slot's lanes and handed round with shuffles
         float tau_slot = METRIC == 1 ? -1.0f : HUGE_VALF;  // an empty slot never passes
         int32_t qid_slot = -1;
         if (qs >= 0) {
             tau_slot = dec_f32(__hip_atomic_load(&p.tau[qs], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             qid_slot = p.qids ? p.qids[qs] : -1;
         }
+        const float qr_slot = sqrtf(qn_slot) * 1.004f;                // upper bound of |q|
+        const float cqr_slot = cq * qr_slot;
+        const float st_slot = sqrtf(fmaxf(tau_slot, 0.f));
+        // l2: sqrt(tau) + eta, minus the row part; dot: the |q| bound itself
+        const float hib_slot = METRIC == 1 ? st_slot + cqr_slot : qr_slot;
+        const float trg_slot = 0.985f * st_slot - cqr_slot;           // trigger level for tightening
         f32x4 acc[4];
 #pragma unroll
         for (int rb = 0; rb < 4; rb++) acc[rb] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1159,32 +1170,34 @@ __global__ __launch_bounds__(256, 4) void k_leafscan_bf16(LeafScanParams p, cons
             const float qnq = __shfl(qn_slot, slot);
             const int32_t qq = __shfl(qs, slot);
             const int32_t qidq = __shfl(qid_slot, slot);
-            const float qr = sqrtf(qnq) * 1.004f;            // upper bound of |q|
-            const float st = METRIC == 1 ? sqrtf(fmaxf(tq, 0.f)) : 0.f;
-            const float sdeep = METRIC == 1 ? sqrtf(fmaxf(0.85f * tq, 0.f)) : 0.f;
+            const float hib = __shfl(hib_slot, slot);
+            const float trg = __shfl(trg_slot, slot);
+            const float cqrq = __shfl(cqr_slot, slot);
+            const bool qok = qq >= 0 && (METRIC == 1 ? tq >= 0.f : true);
+            float v[4];
             int tight = 0;
 #pragma unroll
             for (int rb = 0; rb < 4; rb++) {
                 const float dotv = acc[rb][r];
-                const bool ok = idj[rb] >= 0 && qq >= 0 && tq >= (METRIC == 1 ? 0.f : -HUGE_VALF) &&
-                                !self_excluded(idj[rb], qidq, p.exclude_self);
-                bool pass, deep;
+                const bool ok = qok && idj[rb] >= 0 && !self_excluded(idj[rb], qidq, p.exclude_self);
+                bool pass;
                 if (METRIC == 1) {
-                    const float s = (qnq + xn[rb]) - 2.0f * dotv;
-                    const float slack32 = c32 * (qnq + xn[rb]);
-                    const float eta = cq * (qr + xr[rb]);
-                    const float hi = st + eta;
-                    pass = (s - slack32) <= hi * hi * 1.000001f;
-                    // exact sqrt(d) <= sqrt(s + slack32) + eta; provably below sqrt(0.85 tau)?
-                    const float lo = sdeep - eta;
-                    deep = lo > 0.f && (s + slack32) <= lo * lo * 0.999999f;
+                    // s = |q~ - x~|^2 up to fp32 rounding: s_lo <= exact <= s_hi
+                    const float u = qnq + xn[rb];
+                    const float s_lo = fmaf(-2.0f, dotv, u * (1.0f - c32));
+                    const float s_hi = fmaf(-2.0f, dotv, u * (1.0f + c32));
+                    const float hi = hib + cx[rb];
+                    pass = ok && s_lo <= hi * hi * 1.000001f;
+                    // exact sqrt(d) <= sqrt(s_hi) + eta; v orders the rows of this query by that bound
+                    v[rb] = ok ? sqrtf(fmaxf(s_hi, 0.f)) * 1.000001f + cx[rb] : HUGE_VALF;
+                    tight += __popcll(__ballot(v[rb] <= trg) & gmask);
                 } else {
-                    const float slack = (0.00390625f * 1.01f + c32) * qr * xr[rb] + 1e-30f;
-                    pass = dotv + slack >= tq;
-                    deep = false;
+                    // |q~.x~ - q.x| <= 2^-8 |q||x| (quantisation) + fp32 accumulation
+                    const float xr = cx[rb] * (1.0f / cq);
+                    const float slack = (0.00390625f * 1.01f + c32) * hib * xr + 1e-30f;
+                    pass = ok && dotv + slack >= tq;
+                    v[rb] = 0.f;
                 }
-                pass = pass && ok;
-                if (METRIC == 1) tight += __popcll(__ballot(deep && ok) & gmask);
                 const unsigned long long m = __ballot(pass);
                 if (m) {
                     if (pass) {
@@ -1203,11 +1216,28 @@ __global__ __launch_bounds__(256, 4) void k_leafscan_bf16(LeafScanParams p, cons
                     }
                 }
             }
-            if (METRIC == 1 && tight >= p.k && i16 == 0 && qq >= 0) {
-                // >= k distinct rows of this bucket are provably closer than 0.85 * threshold, so the
-                // query's k-th best is too
-                const float thr = 0.85f * tq * (1.0f + 1e-6f);
-                atomicMin(&p.tau[qq], enc_f32(thr));
+            if (METRIC == 1 && tight >= p.k) {
+                // >= k distinct rows of this bucket are provably closer than 0.97 * threshold.  Select
+                // the k-th smallest bound among the 64 (row, query) values this 16-lane group holds;
+                // the query's k-th best distance cannot exceed it.
+                int rank[4] = {0, 0, 0, 0};
+                for (int j = 0; j < 16; j++) {
+                    const int src = 16 * g + j;
+#pragma unroll
+                    for (int ob = 0; ob < 4; ob++) {
+                        const float o = __shfl(v[ob], src);
+#pragma unroll
+                        for (int mb = 0; mb < 4; mb++)
+                            rank[mb] += (o < v[mb] || (o == v[mb] && (j < i16 || (j == i16 && ob < mb)))) ? 1 : 0;
+                    }
+                }
+#pragma unroll
+                for (int mb = 0; mb < 4; mb++) {
+                    if (rank[mb] == p.k - 1 && v[mb] < HUGE_VALF) {
+                        const float b = (v[mb] + cqrq) * 1.000001f;
+                        atomicMin(&p.tau[qq], enc_f32(b * b * 1.000001f));
+                    }
+                }
             }
         }
     }
