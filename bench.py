@@ -58,14 +58,14 @@ def workload(name, n, nq):
     return params, X, Q, pick, steps
 
 
-def pmc_traffic(workload_name, n, nq, world):
+def pmc_traffic(workload_name, n, nq, world, kernel):
     """HBM-side bytes per rerank launch from the committed rocprofv3 PMC passes
     (FETCH_SIZE doubled as gfx950 needs, plus WRITE_SIZE); None when no pass
     matches this configuration."""
     import glob
     if world != 1 or n != 1_000_000 or nq != 10_000:
         return None
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_pmc_traffic.json" % workload_name)))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_%s_pmc_traffic.json" % (workload_name, kernel))))
     if not files:
         return None
     with open(files[-1]) as f:
@@ -131,6 +131,8 @@ def main():
     ap.add_argument("--search-steps", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-recall", action="store_true")
+    ap.add_argument("--rerank", default="auto", choices=["auto", "gather"],
+                    help="auto: bucket-major bf16 scan + exact rerank where it applies; gather: per-query fp64 gather kernel")
     ap.add_argument("--verify", action="store_true", help="rank 0 also runs an unsharded index and compares the merged ids")
     ap.add_argument("--backend", default="nccl", help="nccl (RCCL, one GPU per rank) or gloo (rehearsal: ranks may share a GPU)")
     args = ap.parse_args()
@@ -156,6 +158,8 @@ def main():
             dist.init_process_group("gloo")
 
     params, X, Q, pick, steps = workload(args.workload, args.n, args.nq)
+    if args.rerank == "gather":
+        params["flags"] = 2          # DPF_FLAG_GATHER_ONLY
     if args.search_steps is not None:
         steps = args.search_steps
     n, nq, k = X.shape[0], Q.shape[0], args.k
@@ -223,6 +227,26 @@ def main():
     if world > 1:
         dist.barrier()
 
+    gather = None
+    if rank == 0 and world == 1 and st["last_path"] == 1:
+        # the per-query gather rerank on the same batch (untimed): the kernel SURVEY's rerank roofline
+        # is defined on, and the source of the de-duplicated candidate count
+        from similaritysearchbyrdf_amd._lib import DpfIndex
+        gi = DpfIndex(dict(params, flags=2), metric=args.metric, top_k=k, dtype=np.float32, device=local)
+        gi.fit(X)
+        g_ms = []
+        for _ in range(3):
+            gi.query_topk_device(dqid.data_ptr(), dQ.data_ptr(), nq, steps, k, d_ids.data_ptr(), d_sc.data_ptr(),
+                                 torch.cuda.current_stream().cuda_stream)
+            ms, by = gi.last_rerank_profile()
+            g_ms.append(ms)
+        gst = gi.stats()
+        same = bool(np.array_equal(d_ids.cpu().numpy(), final_ids))
+        gather = {"kernel": "k_rerank", "bound": "hbm", "achieved": by / (float(np.mean(g_ms[1:])) * 1e-3) / 1e9,
+                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by / (float(np.mean(g_ms[1:])) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                  "algorithmic_bytes_per_launch": by, "ms_per_launch": float(np.mean(g_ms[1:])),
+                  "unique_candidates_per_query": gst["last_unique_candidates"] / nq, "same_ids_as_timed_path": same}
+        gi.close()
     if rank == 0:
         rr = float(np.mean(rr_ms))
         achieved = rr_bytes / (rr * 1e-3) / 1e9
@@ -237,14 +261,19 @@ def main():
                                        steps, k, args.metric),
                        "global_batch": nq, "parallelism": "rows%d" % world,
                        "recall_at_10": recall, "fit_seconds": round(fit_s, 2),
-                       "raw_candidates_per_query": st["last_raw_candidates"] / nq,
-                       "unique_candidates_per_query_on_rank0": st["last_unique_candidates"] / nq,
+                       "rerank_path": "bucket-major bf16 scan + exact fp64 rerank" if st["last_path"] == 1 else "gather",
+                       "ids_visited_per_query_on_rank0": st["last_raw_candidates"] / nq,
+                       "unique_candidates_per_query_on_rank0": (st["last_unique_candidates"] / nq) if st["last_path"] == 0 else None,
+                       "bucket_incidences_per_query_on_rank0": st["last_pairs"] / nq,
+                       "forwarded_to_exact_rerank_per_query_on_rank0": st["last_forwarded"] / nq,
                        "misflag_events": st["misflag_events"], "short_hash_events": st["short_hash_events"]},
-            "roofline": {"bound": "hbm", "kernel": "k_rerank", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "k_leafscan_bf16" if st["last_path"] == 1 else "k_rerank", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(args.workload, n, nq, world),
+                         "traffic": pmc_traffic(args.workload, n, nq, world, "k_leafscan_bf16" if st["last_path"] == 1 else "k_rerank"),
                          "algorithmic_bytes_per_launch": rr_bytes, "ms_per_launch": rr},
         }
+        if gather is not None:
+            out["roofline_gather_rerank"] = gather
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(params, X, Q, pick, steps, k, args.metric)
         print(json.dumps(out), flush=True)

@@ -166,9 +166,12 @@ int dpf_subindex_distribution(dpf_index *ix, double *out);
 
 int dpf_get_stats(dpf_index *ix, dpf_stats *out);
 
-/* Device time of the dominant (rerank) kernel in the last *_topk* call, measured
- * with HIP events on the stream the kernel ran on; and the bytes that launch
- * had to move by definition (candidate rows + ids + queries + results). */
+/* Device time of the dominant kernel of the last *_topk* call, measured with HIP
+ * events on the stream the kernel ran on, and the bytes that launch has to move by
+ * its own definition: the gather rerank (dpf_stats.last_path 0) reads every
+ * candidate row + id, the query rows, and writes the results; the bucket-major
+ * scan (last_path 1) reads every touched bucket's rows + ids once, one query row +
+ * threshold per (query, bucket) incidence, and writes the forwarded pairs. */
 int dpf_last_rerank_profile(dpf_index *ix, double *ms, int64_t *algorithmic_bytes);
 /* enable (1) / disable (0) the per-stage HIP-event timing (adds stream syncs) */
 int dpf_set_profiling(dpf_index *ix, int32_t on);

@@ -65,6 +65,7 @@ struct dpf_index {
     DevBuf d_base16, ws_q16;                 // bf16 copies of the resident rows / of the query batch
     int ks16 = -1;                           // 32-dimension bf16 steps per padded row (-1: no bf16 scan)
     int64_t ntiles = 0, num_leaves = 0;
+    std::vector<uint32_t> h_leaf_len;        // rows per bucket of the uploaded snapshot
     double maxnorm = 0.0;                    // largest base-row norm seen by dpf_fit
     bool bucket_major = false;               // the bucket-major rerank applies to this handle
     bool fitted = false;
@@ -332,6 +333,8 @@ static int upload_snapshot(dpf_index *ix, ForestSnapshot &s)
         }
     }
     if ((rc = upload(ix, ix->d_tiles, tiles)) != DPF_OK) return rc;
+    ix->h_leaf_len.resize(s.leaf_off.size() - 1);
+    for (size_t l = 0; l + 1 < s.leaf_off.size(); l++) ix->h_leaf_len[l] = s.leaf_off[l + 1] - s.leaf_off[l];
     ix->ntiles = (int64_t)tile_leaf.size();
     ix->num_leaves = (int64_t)s.leaf_off.size() - 1;
     if ((rc = upload(ix, ix->d_tile_leaf, tile_leaf)) != DPF_OK) return rc;
@@ -909,8 +912,20 @@ extern "C" int dpf_last_rerank_profile(dpf_index *ix, double *ms, int64_t *algor
     int rc = last_totals(ix, &raw, &uniq);
     if (rc != DPF_OK) return rc;
     if (ms) *ms = t;
-    // candidate rows + candidate ids + query rows + (score, id) results
     const int64_t row = (int64_t)ix->cfg.dim * (int64_t)ix->elem;
+    if (ix->last_path == 1) {
+        // bucket-major scan: every touched bucket's rows and ids once, one query row + threshold +
+        // ids per (query, bucket) incidence, one (query, id) pair per forwarded candidate
+        std::vector<uint32_t> c((size_t)ix->num_leaves);
+        HIPCHECK(ix, hipMemcpy(c.data(), ix->ws_lq_cnt.p, c.size() * 4, hipMemcpyDeviceToHost));
+        int64_t touched_rows = 0;
+        for (size_t l = 0; l < c.size(); l++)
+            if (c[l]) touched_rows += ix->h_leaf_len[l];
+        const int64_t srow = ix->ks16 > 0 && !getenv("DPF_LEAFSCAN") ? (int64_t)ix->ks16 * 64 : ix->dpad * 4;
+        if (algorithmic_bytes) *algorithmic_bytes = touched_rows * (srow + 4) + ix->st.last_pairs * (srow + 12) + uniq * 8;
+        return DPF_OK;
+    }
+    // gather rerank: candidate rows + candidate ids + query rows + (score, id) results
     if (algorithmic_bytes) *algorithmic_bytes = uniq * (row + 4) + ix->last_nq * row + ix->last_nq * (int64_t)ix->last_k * 12;
     return DPF_OK;
 }

@@ -2,7 +2,7 @@
 //
 //   k_hash        LSH projection + hash assembly + sub-index id      (fp64 VALU, exact order)
 //   k_probe       multi-probe / multi-step trie walk; counts or sets candidate bits
-//   k_scan        exclusive scan of per-query candidate bounds
+//   k_scan_*      exclusive scan (per-query candidate bounds, per-bucket query counts)
 //   k_rerank      candidate-row gather + distance + per-query top-k  (HBM-bound)
 //   k_merge_topk  merge of partial top-k lists
 //   k_compact     gathers the per-query sets into one CSR array
@@ -474,17 +474,44 @@ void launch_probe(int mode, const ProbeParams &p, int64_t nq, hipStream_t stream
 }
 
 // ---------------------------------------------------------------------------
-// k_scan: off[0] = 0, off[i+1] = off[i] + in[i]   (single workgroup)
+// k_scan_*: off[0] = 0, off[i+1] = off[i] + in[i], in three launches:
+//   sums   each workgroup adds up its SCAN_TILE inputs and parks the sum in off[] at
+//          the tile's first slot (no scratch buffer: off[] is rewritten by the last phase)
+//   tiles  one workgroup turns the parked sums into exclusive tile bases, writes off[n]
+//   apply  each workgroup picks up its base and scans its tile
 // ---------------------------------------------------------------------------
+static constexpr int SCAN_THREADS = 256, SCAN_PER = 8, SCAN_TILE = SCAN_THREADS * SCAN_PER;
+
+__device__ __forceinline__ int64_t block_sum256(int64_t v, int64_t *sh)
+{
+    for (int o = 32; o; o >>= 1) v += __shfl_down(v, o);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
 template <typename TIN>
-__global__ __launch_bounds__(1024) void k_scan(const TIN *__restrict__ in, int64_t n, int64_t *__restrict__ off)
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_sums(const TIN *__restrict__ in, int64_t n, int64_t *__restrict__ off)
+{
+    __shared__ int64_t sh[4];
+    const int64_t t0 = (int64_t)blockIdx.x * SCAN_TILE;
+    int64_t s = 0;
+    for (int j = 0; j < SCAN_PER; j++) {
+        const int64_t i = t0 + j * SCAN_THREADS + threadIdx.x;
+        if (i < n) s += (int64_t)in[i];
+    }
+    s = block_sum256(s, sh);
+    if (threadIdx.x == 0) off[t0] = s;
+}
+
+__global__ __launch_bounds__(1024) void k_scan_tiles(int64_t n, int64_t ntiles, int64_t *__restrict__ off)
 {
     __shared__ int64_t part[1024];
     const int tid = threadIdx.x;
-    const int64_t per = (n + 1023) / 1024;
-    const int64_t b = tid * per, e = (b + per < n) ? b + per : n;
+    const int64_t per = (ntiles + 1023) / 1024;
+    const int64_t b = tid * per, e = (b + per < ntiles) ? b + per : ntiles;
     int64_t s = 0;
-    for (int64_t i = b; i < e; i++) s += (int64_t)in[i];
+    for (int64_t i = b; i < e; i++) s += off[i * SCAN_TILE];
     part[tid] = s;
     __syncthreads();
     for (int o = 1; o < 1024; o <<= 1) {
@@ -494,18 +521,42 @@ __global__ __launch_bounds__(1024) void k_scan(const TIN *__restrict__ in, int64
         __syncthreads();
     }
     int64_t run = part[tid] - s;
-    for (int64_t i = b; i < e; i++) { off[i] = run; run += (int64_t)in[i]; }
+    for (int64_t i = b; i < e; i++) { const int64_t v = off[i * SCAN_TILE]; off[i * SCAN_TILE] = run; run += v; }
     if (tid == 1023) off[n] = part[1023];
 }
 
-void launch_scan_i64(const int64_t *in, int64_t n, int64_t *off, hipStream_t stream)
+template <typename TIN>
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(const TIN *__restrict__ in, int64_t n, int64_t *__restrict__ off)
 {
-    hipLaunchKernelGGL((k_scan<int64_t>), dim3(1), dim3(1024), 0, stream, in, n, off);
+    __shared__ int64_t wsum[4];
+    const int64_t t0 = (int64_t)blockIdx.x * SCAN_TILE;
+    const int64_t base = off[t0];
+    // thread t owns inputs t*SCAN_PER .. t*SCAN_PER+SCAN_PER-1 of the tile
+    int64_t v[SCAN_PER], s = 0;
+    const int64_t i0 = t0 + (int64_t)threadIdx.x * SCAN_PER;
+#pragma unroll
+    for (int j = 0; j < SCAN_PER; j++) { v[j] = i0 + j < n ? (int64_t)in[i0 + j] : 0; s += v[j]; }
+    int64_t inc = s;                                  // inclusive scan over the wave
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int o = 1; o < 64; o <<= 1) { const int64_t u = __shfl_up(inc, o); if (lane >= o) inc += u; }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();                                  // also orders the read of off[t0] before the writes below
+    int64_t run = base + inc - s;
+    for (int u = 0; u < w; u++) run += wsum[u];
+#pragma unroll
+    for (int j = 0; j < SCAN_PER; j++) { if (i0 + j < n) off[i0 + j] = run; run += v[j]; }
 }
-void launch_scan_i32(const int32_t *in, int64_t n, int64_t *off, hipStream_t stream)
+
+template <typename TIN>
+static void launch_scan(const TIN *in, int64_t n, int64_t *off, hipStream_t stream)
 {
-    hipLaunchKernelGGL((k_scan<int32_t>), dim3(1), dim3(1024), 0, stream, in, n, off);
+    const int64_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+    if (ntiles > 0) hipLaunchKernelGGL((k_scan_sums<TIN>), dim3((unsigned)ntiles), dim3(SCAN_THREADS), 0, stream, in, n, off);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, stream, n, ntiles, off);
+    if (ntiles > 0) hipLaunchKernelGGL((k_scan_apply<TIN>), dim3((unsigned)ntiles), dim3(SCAN_THREADS), 0, stream, in, n, off);
 }
+void launch_scan_i64(const int64_t *in, int64_t n, int64_t *off, hipStream_t stream) { launch_scan(in, n, off, stream); }
+void launch_scan_i32(const int32_t *in, int64_t n, int64_t *off, hipStream_t stream) { launch_scan(in, n, off, stream); }
 
 // ---------------------------------------------------------------------------
 // k_compact: dst[dst_off[q] + j] = src[src_off[q] + j], j < cnt[q]
@@ -1081,6 +1132,8 @@ __global__ __launch_bounds__(256, LS16_WAVES) void k_leafscan_bf16(LeafScanParam
                                                                    const uint16_t *__restrict__ B16)
 {
     __shared__ int32_t s_fq[4][128], s_fid[4][128];
+    __shared__ float4 s_slot[4][16];                      // per query slot: {G, G2, bits of query index, bits of query id}
+    __shared__ float2 s_slot2[4][16];                     // {|q~|^2, 2^-9 |q| bound}
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
     if (tile >= p.ntiles) return;
@@ -1092,7 +1145,9 @@ __global__ __launch_bounds__(256, LS16_WAVES) void k_leafscan_bf16(LeafScanParam
     constexpr int STRIDE = KS * 32;                       // bf16 elements per padded row
     const unsigned long long lt = (1ull << lane) - 1ull;
     const unsigned long long gmask = 0xffffull << (16 * g);
-    const float c32 = 3.0f * (float)(STRIDE + 8) * 5.9604645e-8f;    // fp32 accumulation, per unit of |q|^2+|x|^2
+    // fp32 accumulation of the products and of the norms plus the roundings of the threshold
+    // arithmetic below, per unit of |q~|^2 + |x~|^2
+    const float c32 = (3.0f * (float)(STRIDE + 8) + 24.0f) * 5.9604645e-8f;
     const float cq = 0.001953125f * 1.002f;                          // 2^-9 with room for the rounded norms
 
     int nbuf = 0;
@@ -1106,7 +1161,8 @@ __global__ __launch_bounds__(256, LS16_WAVES) void k_leafscan_bf16(LeafScanParam
 
     bf16x8 xb[4][KS];
     int32_t idj[4];
-    float xn[4], cx[4];                                   // |x~|^2 and 2^-9 * (upper bound of |x|)
+    float xn[4], J[4];                                    // |x~|^2; the row's share of the threshold
+    float xnm = 0.f;
 #pragma unroll
     for (int rb = 0; rb < 4; rb++) {
         const uint32_t idx = rb * 16 + i16;
@@ -1123,8 +1179,13 @@ __global__ __launch_bounds__(256, LS16_WAVES) void k_leafscan_bf16(LeafScanParam
         s += __shfl_xor(s, 16);
         s += __shfl_xor(s, 32);
         xn[rb] = s;
-        cx[rb] = cq * sqrtf(s) * 1.004f;
+        // an absent row never reaches any threshold
+        J[rb] = id >= 0 ? (METRIC == 1 ? 0.5f * s * (1.0f - c32) : 0.f) : HUGE_VALF;
+        if (id >= 0) xnm = fmaxf(xnm, s);
     }
+    for (int o = 1; o < 16; o <<= 1) xnm = fmaxf(xnm, __shfl_xor(xnm, o));   // bits 16 and 32 only permute equal copies
+    const float xrm = sqrtf(xnm) * 1.004f;               // upper bound of the largest |x| of the tile
+    const float cxm = cq * xrm;
 
     int32_t qs_next = (lqb + i16 < lqe) ? p.leaf_queries[lqb + i16] : -1;
     for (int64_t q0 = lqb; q0 < lqe; q0 += 16) {
@@ -1142,19 +1203,35 @@ __global__ __launch_bounds__(256, LS16_WAVES) void k_leafscan_bf16(LeafScanParam
             qn_slot += __shfl_xor(qn_slot, 16);
             qn_slot += __shfl_xor(qn_slot, 32);
         }
-        // per-slot constants, computed once by the slot's lanes and handed round with shuffles
-        float tau_slot = METRIC == 1 ? -1.0f : HUGE_VALF;  // an empty slot never passes
-        int32_t qid_slot = -1;
-        if (qs >= 0) {
-            tau_slot = dec_f32(__hip_atomic_load(&p.tau[qs], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            qid_slot = p.qids ? p.qids[qs] : -1;
+        // Per-slot thresholds on d = q~.x~ - J(row), computed once by the slot's lane.
+        //   l2:  forward when |q~ - x~|^2 could be <= (sqrt(tau) + eta)^2, eta <= 2^-9 (|q| + |x|max):
+        //        q~.x~ - |x~|^2/2 >= (|q~|^2 - (sqrt(tau) + eta)^2) / 2 =: G, rounding taken on the safe side
+        //   dot: forward when q~.x~ + 2^-8 |q||x|max >= tau
+        // G2 is the level at which a row is roughly inside 0.985 sqrt(tau); it only triggers the
+        // exact selection below, so it needs no rigour.
+        if (g == 0) {
+            float G = HUGE_VALF, G2 = HUGE_VALF, cqr = 0.f;
+            int32_t qid = -1;
+            if (qs >= 0) {
+                const float tau = dec_f32(__hip_atomic_load(&p.tau[qs], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                qid = p.qids ? p.qids[qs] : -1;
+                const float qr = sqrtf(qn_slot) * 1.004f;            // upper bound of |q|
+                cqr = cq * qr;
+                if (METRIC == 1) {
+                    if (tau >= 0.f) {
+                        const float st = sqrtf(tau);
+                        const float hi = st + cqr + cxm;
+                        G = fmaxf(0.5f * (qn_slot * (1.0f - c32) - hi * hi * 1.000001f), -3.0e38f);
+                        const float w = 0.985f * st - cqr - cxm;
+                        if (w > 0.f) G2 = fmaxf(0.5f * (qn_slot * (1.0f + c32) - w * w) + c32 * xnm, -3.0e38f);
+                    }
+                } else {
+                    G = fmaxf(tau - (0.00390625f * 1.01f + c32) * qr * xrm - 1e-30f, -3.0e38f);
+                }
+            }
+            s_slot[wave][i16] = make_float4(G, G2, __int_as_float(qs), __int_as_float(qid));
+            s_slot2[wave][i16] = make_float2(qn_slot, cqr);
         }
-        const float qr_slot = sqrtf(qn_slot) * 1.004f;                // upper bound of |q|
-        const float cqr_slot = cq * qr_slot;
-        const float st_slot = sqrtf(fmaxf(tau_slot, 0.f));
-        // l2: sqrt(tau) + eta, minus the row part; dot: the |q| bound itself
-        const float hib_slot = METRIC == 1 ? st_slot + cqr_slot : qr_slot;
-        const float trg_slot = 0.985f * st_slot - cqr_slot;           // trigger level for tightening
         f32x4 acc[4];
 #pragma unroll
         for (int rb = 0; rb < 4; rb++) acc[rb] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1166,60 +1243,56 @@ __global__ __launch_bounds__(256, LS16_WAVES) void k_leafscan_bf16(LeafScanParam
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int slot = 4 * g + r;
-            const float tq = __shfl(tau_slot, slot);
-            const float qnq = __shfl(qn_slot, slot);
-            const int32_t qq = __shfl(qs, slot);
-            const int32_t qidq = __shfl(qid_slot, slot);
-            const float hib = __shfl(hib_slot, slot);
-            const float trg = __shfl(trg_slot, slot);
-            const float cqrq = __shfl(cqr_slot, slot);
-            const bool qok = qq >= 0 && (METRIC == 1 ? tq >= 0.f : true);
-            float v[4];
+            const float4 sc = s_slot[wave][slot];
+            float d[4];
+            bool pass[4];
             int tight = 0;
+            unsigned long long many = 0;
 #pragma unroll
             for (int rb = 0; rb < 4; rb++) {
-                const float dotv = acc[rb][r];
-                const bool ok = qok && idj[rb] >= 0 && !self_excluded(idj[rb], qidq, p.exclude_self);
-                bool pass;
-                if (METRIC == 1) {
-                    // s = |q~ - x~|^2 up to fp32 rounding: s_lo <= exact <= s_hi
-                    const float u = qnq + xn[rb];
-                    const float s_lo = fmaf(-2.0f, dotv, u * (1.0f - c32));
-                    const float s_hi = fmaf(-2.0f, dotv, u * (1.0f + c32));
-                    const float hi = hib + cx[rb];
-                    pass = ok && s_lo <= hi * hi * 1.000001f;
-                    // exact sqrt(d) <= sqrt(s_hi) + eta; v orders the rows of this query by that bound
-                    v[rb] = ok ? sqrtf(fmaxf(s_hi, 0.f)) * 1.000001f + cx[rb] : HUGE_VALF;
-                    tight += __popcll(__ballot(v[rb] <= trg) & gmask);
-                } else {
-                    // |q~.x~ - q.x| <= 2^-8 |q||x| (quantisation) + fp32 accumulation
-                    const float xr = cx[rb] * (1.0f / cq);
-                    const float slack = (0.00390625f * 1.01f + c32) * hib * xr + 1e-30f;
-                    pass = ok && dotv + slack >= tq;
-                    v[rb] = 0.f;
-                }
-                const unsigned long long m = __ballot(pass);
-                if (m) {
-                    if (pass) {
-                        const int at = nbuf + __popcll(m & lt);
-                        s_fq[wave][at] = qq;
-                        s_fid[wave][at] = idj[rb];
-                    }
-                    nbuf += __popcll(m);
-                    if (nbuf >= 64) {
-                        flush(64);
-                        const int rest = nbuf - 64;
-                        int32_t tq2 = 0, ti2 = 0;
-                        if (lane < rest) { tq2 = s_fq[wave][64 + lane]; ti2 = s_fid[wave][64 + lane]; }
-                        if (lane < rest) { s_fq[wave][lane] = tq2; s_fid[wave][lane] = ti2; }
-                        nbuf = rest;
+                d[rb] = acc[rb][r] - J[rb];
+                pass[rb] = d[rb] >= sc.x;
+                many |= __ballot(pass[rb]);
+                if (METRIC == 1) tight += __popcll(__ballot(d[rb] >= sc.y) & gmask);
+            }
+            if (many) {
+                const int32_t qq = __float_as_int(sc.z), qidq = __float_as_int(sc.w);
+#pragma unroll
+                for (int rb = 0; rb < 4; rb++) {
+                    const bool fwd = pass[rb] && !self_excluded(idj[rb], qidq, p.exclude_self);
+                    const unsigned long long m = __ballot(fwd);
+                    if (m) {
+                        if (fwd) {
+                            const int at = nbuf + __popcll(m & lt);
+                            s_fq[wave][at] = qq;
+                            s_fid[wave][at] = idj[rb];
+                        }
+                        nbuf += __popcll(m);
+                        if (nbuf >= 64) {
+                            flush(64);
+                            const int rest = nbuf - 64;
+                            int32_t tq2 = 0, ti2 = 0;
+                            if (lane < rest) { tq2 = s_fq[wave][64 + lane]; ti2 = s_fid[wave][64 + lane]; }
+                            if (lane < rest) { s_fq[wave][lane] = tq2; s_fid[wave][lane] = ti2; }
+                            nbuf = rest;
+                        }
                     }
                 }
             }
             if (METRIC == 1 && tight >= p.k) {
-                // >= k distinct rows of this bucket are provably closer than 0.97 * threshold.  Select
-                // the k-th smallest bound among the 64 (row, query) values this 16-lane group holds;
-                // the query's k-th best distance cannot exceed it.
+                // Roughly k or more rows of this tile sit inside 0.985 sqrt(tau).  With
+                //   v = sqrt(s_hi) + 2^-9 |x|max >= sqrt(exact distance) - 2^-9 |q|
+                // (s_hi = |q~ - x~|^2 rounded up), the k-th smallest v among the 64 rows this 16-lane
+                // group holds for the query bounds the query's k-th best distance from above.
+                const int32_t qq = __float_as_int(sc.z), qidq = __float_as_int(sc.w);
+                const float2 s2 = s_slot2[wave][slot];
+                float v[4];
+#pragma unroll
+                for (int rb = 0; rb < 4; rb++) {
+                    const bool ok = idj[rb] >= 0 && !self_excluded(idj[rb], qidq, p.exclude_self);
+                    const float s_hi = fmaf(-2.0f, acc[rb][r], (s2.x + xn[rb]) * (1.0f + c32));
+                    v[rb] = ok ? sqrtf(fmaxf(s_hi, 0.f)) * 1.000001f + cxm : HUGE_VALF;
+                }
                 int rank[4] = {0, 0, 0, 0};
                 for (int j = 0; j < 16; j++) {
                     const int src = 16 * g + j;
@@ -1234,7 +1307,7 @@ __global__ __launch_bounds__(256, LS16_WAVES) void k_leafscan_bf16(LeafScanParam
 #pragma unroll
                 for (int mb = 0; mb < 4; mb++) {
                     if (rank[mb] == p.k - 1 && v[mb] < HUGE_VALF) {
-                        const float b = (v[mb] + cqrq) * 1.000001f;
+                        const float b = (v[mb] + s2.y) * 1.000001f;
                         atomicMin(&p.tau[qq], enc_f32(b * b * 1.000001f));
                     }
                 }
