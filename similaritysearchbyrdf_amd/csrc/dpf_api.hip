@@ -60,10 +60,15 @@ struct dpf_index {
     int64_t base_rows = 0;                   // resident rows: ids row_begin .. row_begin+base_rows-1
 
     DevBuf d_roots, d_dnodes, d_leaf_off, d_ids;
+    DevBuf ws_emit_v;
+    DevBuf d_leaf_tile0, ws_units;           // first tile of each bucket; work units of the batch
+    int num_cus = 256;
     DevBuf d_tiles;                          // {bucket, first id slot, rows, 0} per tile
     DevBuf d_tile_leaf, d_tile_row0;         // 64-row tiles of the buckets (bucket-major scan)
-    DevBuf d_base16, ws_q16;                 // bf16 copies of the resident rows / of the query batch
-    int ks16 = -1;                           // 32-dimension bf16 steps per padded row (-1: no bf16 scan)
+    DevBuf d_base16e, ws_q16e;               // distances between the rows and their fp16 copies
+    DevBuf d_base16n, ws_q16n;               // their squared norms
+    DevBuf d_base16, ws_q16;                 // fp16 copies of the resident rows / of the query batch
+    int ks16 = -1;                           // 32-dimension fp16 steps per padded row (-1: no fp16 scan)
     int64_t ntiles = 0, num_leaves = 0;
     std::vector<uint32_t> h_leaf_len;        // rows per bucket of the uploaded snapshot
     double maxnorm = 0.0;                    // largest base-row norm seen by dpf_fit
@@ -149,7 +154,7 @@ extern "C" int dpf_create(const dpf_config *cfg, dpf_index **out)
     if (cfg->dtype == DPF_F32 && !(cfg->flags & DPF_FLAG_GATHER_ONLY) && !getenv("DPF_GATHER_ONLY")) {
         // rows padded to a piece count the bucket-major scan is instantiated for
         const int nc = leafscan_padded_chunks((int)(ix->dpad / 4));
-        if (nc > 0) { ix->dpad = (int64_t)nc * 4; ix->bucket_major = true; ix->ks16 = leafscan_bf16_steps(cfg->dim); }
+        if (nc > 0) { ix->dpad = (int64_t)nc * 4; ix->bucket_major = true; ix->ks16 = leafscan_f16_steps(cfg->dim); }
     }
     if (ix->dpad * (int64_t)ix->elem / 16 > rerank_max_chunks16()) { delete ix; return fail(nullptr, DPF_EINVAL, "dpf_create: dim too large for the rerank kernel"); }
     resolve_rows(ix);
@@ -160,6 +165,7 @@ extern "C" int dpf_create(const dpf_config *cfg, dpf_index **out)
     if (cfg->device < 0 || cfg->device >= ndev) { delete ix; return fail(nullptr, DPF_EINVAL, "dpf_create: bad device ordinal"); }
     e = hipSetDevice(cfg->device);
     if (e == hipSuccess && configure_kernels() != 0) e = hipErrorInvalidValue;
+    if (e == hipSuccess) { int v = 0; e = hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, cfg->device); if (v > 0) ix->num_cus = v; }
     if (e == hipSuccess) e = hipMalloc((void **)&ix->d_short_hash, sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(ix->d_short_hash, 0, sizeof(unsigned long long));
     if (e == hipSuccess) e = hipHostMalloc((void **)&ix->pinned, 8 * sizeof(int64_t), hipHostMallocDefault);
@@ -202,9 +208,9 @@ extern "C" void dpf_destroy(dpf_index *ix)
     if (ix->pinned) (void)hipHostFree(ix->pinned);
     for (int i = 0; i < 6; i++) if (ix->ev[i]) (void)hipEventDestroy(ix->ev[i]);
     for (int i = 0; i < 2; i++) if (ix->ev_scan[i]) (void)hipEventDestroy(ix->ev_scan[i]);
-    DevBuf *more[] = {&ix->d_tiles, &ix->d_tile_leaf, &ix->d_tile_row0, &ix->ws_lq_cnt, &ix->ws_lq_off, &ix->ws_lq_cursor, &ix->ws_leaf_queries,
+    DevBuf *more[] = {&ix->ws_emit_v, &ix->d_leaf_tile0, &ix->ws_units, &ix->d_tiles, &ix->d_tile_leaf, &ix->d_tile_row0, &ix->ws_lq_cnt, &ix->ws_lq_off, &ix->ws_lq_cursor, &ix->ws_leaf_queries,
                       &ix->ws_seed_cand, &ix->ws_seed_cnt, &ix->ws_seed_ids, &ix->ws_seed_scores, &ix->ws_emit, &ix->ws_emit_cnt,
-                      &ix->d_base16, &ix->ws_q16, &ix->ws_flag, &ix->ws_qnorm, &ix->ws_tau, &ix->ws_slack};
+                      &ix->d_base16, &ix->ws_q16, &ix->d_base16n, &ix->ws_q16n, &ix->d_base16e, &ix->ws_q16e, &ix->ws_flag, &ix->ws_qnorm, &ix->ws_tau, &ix->ws_slack};
     for (DevBuf *b : more) b->release();
     delete ix;
 }
@@ -323,16 +329,19 @@ static int upload_snapshot(dpf_index *ix, ForestSnapshot &s)
         s.ids.swap(ids);
         s.leaf_off.swap(off);
     }
-    std::vector<uint32_t> tile_leaf, tile_row0, tiles;
+    std::vector<uint32_t> tile_leaf, tile_row0, tiles, leaf_tile0(s.leaf_off.size(), 0u);
     for (size_t l = 0; l + 1 < s.leaf_off.size(); l++) {
         const uint32_t len = s.leaf_off[l + 1] - s.leaf_off[l];
+        leaf_tile0[l] = (uint32_t)tile_leaf.size();
         for (uint32_t r = 0; r < len; r += 64) {
             tile_leaf.push_back((uint32_t)l);
             tile_row0.push_back(r);
             tiles.push_back((uint32_t)l); tiles.push_back(s.leaf_off[l] + r); tiles.push_back(std::min<uint32_t>(64u, len - r)); tiles.push_back(0u);
         }
     }
+    leaf_tile0.back() = (uint32_t)tile_leaf.size();
     if ((rc = upload(ix, ix->d_tiles, tiles)) != DPF_OK) return rc;
+    if ((rc = upload(ix, ix->d_leaf_tile0, leaf_tile0)) != DPF_OK) return rc;
     ix->h_leaf_len.resize(s.leaf_off.size() - 1);
     for (size_t l = 0; l + 1 < s.leaf_off.size(); l++) ix->h_leaf_len[l] = s.leaf_off[l + 1] - s.leaf_off[l];
     ix->ntiles = (int64_t)tile_leaf.size();
@@ -348,6 +357,11 @@ static int upload_snapshot(dpf_index *ix, ForestSnapshot &s)
     ix->st.max_leaf = s.max_leaf;
     ix->st.misflag_events = s.misflag_events;
     ix->st.snapshot_bytes = (int64_t)(s.roots.size() * 4 + s.dnodes.size() * 4 + s.leaf_off.size() * 4 + s.ids.size() * 4);
+    if (ix->bucket_major && ix->ks16 > 0 && ix->ntiles > 0 && ix->base_rows > 0) {
+        launch_tile_maxnorm((uint4 *)ix->d_tiles.p, ix->ntiles, ix->d_ids.as<int32_t>(), ix->d_base16n.as<float>(), ix->d_base16e.as<float>(),
+                            ix->row_begin, ix->row_begin + ix->base_rows, nullptr);
+        HIPCHECK(ix, hipDeviceSynchronize());
+    }
     return DPF_OK;
 }
 
@@ -416,7 +430,10 @@ extern "C" int dpf_fit(dpf_index *ix, const void *X, int64_t n)
     }
     if (ix->bucket_major && ix->ks16 > 0 && new_rows > 0) {
         HIPCHECK(ix, ix->d_base16.ensure((size_t)new_rows * ix->ks16 * 32 * 2));
-        launch_rows_to_bf16(ix->d_base.as<float>(), ix->dpad, d, new_rows, ix->d_base16.as<uint16_t>(), ix->ks16 * 32, nullptr);
+        HIPCHECK(ix, ix->d_base16n.ensure((size_t)new_rows * 4));
+        HIPCHECK(ix, ix->d_base16e.ensure((size_t)new_rows * 4));
+        launch_rows_to_f16(ix->d_base.as<float>(), ix->dpad, d, new_rows, ix->d_base16.as<uint16_t>(), ix->ks16 * 32,
+                            ix->d_base16n.as<float>(), ix->d_base16e.as<float>(), nullptr);
     }
     HIPCHECK(ix, hipDeviceSynchronize());
     ix->base_rows = new_rows;
@@ -538,7 +555,7 @@ static void fill_rerank_params(dpf_index *ix, RerankParams &rp, const void *d_Qp
     rp.out_ids = d_ids; rp.out_scores = d_scores;
 }
 
-static const int32_t SEED_CAP = 1024;     // seed sample per query (ids from table 0's buckets)
+static const int32_t SEED_CAP = getenv("DPF_SEED_CAP") ? atoi(getenv("DPF_SEED_CAP")) : 256;     // seed sample per query
 // forwarded candidates per query before the gather path takes over (DPF_EMIT_CAP overrides, for tests)
 static int32_t emit_cap_setting()
 {
@@ -571,7 +588,7 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     HIPCHECK(ix, ix->ws_seed_scores.ensure((size_t)nq * k * 8));
     HIPCHECK(ix, ix->ws_emit.ensure((size_t)nq * EMIT_CAP * 4));
     HIPCHECK(ix, ix->ws_emit_cnt.ensure((size_t)nq * 4));
-    HIPCHECK(ix, ix->ws_flag.ensure(16));
+    HIPCHECK(ix, ix->ws_flag.ensure(32));             // overflow flag, unit count, unit cursor
     HIPCHECK(ix, ix->ws_qnorm.ensure((size_t)nq * 4));
     HIPCHECK(ix, ix->ws_tau.ensure((size_t)nq * 4));
     HIPCHECK(ix, ix->ws_slack.ensure((size_t)nq * 4));
@@ -582,15 +599,21 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     HIPCHECK(ix, hipMemsetAsync(ix->ws_lq_cnt.p, 0, (size_t)(nl + 1) * 4, stream));
     HIPCHECK(ix, hipMemsetAsync(ix->ws_lq_cursor.p, 0, (size_t)(nl + 1) * 4, stream));
     HIPCHECK(ix, hipMemsetAsync(ix->ws_emit_cnt.p, 0, (size_t)nq * 4, stream));
-    HIPCHECK(ix, hipMemsetAsync(ix->ws_flag.p, 0, 16, stream));
+    HIPCHECK(ix, hipMemsetAsync(ix->ws_flag.p, 0, 32, stream));
     ProbeParams pp;
     fill_probe_params(ix, pp, d_qids, steps);
     pp.lq_cnt = ix->ws_lq_cnt.as<uint32_t>();
     launch_probe(0, pp, nq, stream);
     launch_scan_i32(ix->ws_lq_cnt.as<int32_t>(), nl, ix->ws_lq_off.as<int64_t>(), stream);
+    const int engine = [&] { const char *e = getenv("DPF_LEAFSCAN"); return (e && !strcmp(e, "valu")) ? 0 : ((e && !strcmp(e, "f32")) || ix->ks16 < 0 ? 1 : 2); }();
+    unsigned long long *d_unit_count = (unsigned long long *)ix->ws_flag.p + 1, *d_unit_cursor = d_unit_count + 1;
+    if (engine == 2) launch_unit_count(ix->ws_lq_cnt.as<uint32_t>(), ix->d_leaf_tile0.as<uint32_t>(), nl, d_unit_count, stream);
     HIPCHECK(ix, hipMemcpyAsync(ix->pinned, ix->ws_lq_off.as<int64_t>() + nl, 8, hipMemcpyDeviceToHost, stream));
+    HIPCHECK(ix, hipMemcpyAsync(ix->pinned + 2, d_unit_count, 8, hipMemcpyDeviceToHost, stream));
     HIPCHECK(ix, hipStreamSynchronize(stream));
-    const int64_t pairs = ix->pinned[0];
+    const int64_t pairs = ix->pinned[0], nunits = ix->pinned[2];
+    // unit descriptors index leaf_queries[] and the unit list with 32 bits
+    if (pairs >= (int64_t)0xffffffffll || nunits >= (int64_t)0xffffffffll) return DPF_OK;
     if (getenv("DPF_DEBUG")) {
         std::vector<uint32_t> c((size_t)nl);
         HIPCHECK(ix, hipMemcpy(c.data(), ix->ws_lq_cnt.p, (size_t)nl * 4, hipMemcpyDeviceToHost));
@@ -598,6 +621,9 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
         std::sort(srt.begin(), srt.end());
         size_t touched = 0;
         for (auto v : c) touched += v > 0;
+        size_t ttiles = 0;
+        for (size_t l = 0; l < c.size(); l++) if (c[l]) ttiles += (ix->h_leaf_len[l] + 63) / 64;
+        fprintf(stderr, "[dpf] tiles %lld touched %zu units %lld\n", (long long)ix->ntiles, ttiles, (long long)nunits);
         fprintf(stderr, "[dpf] buckets %lld touched %zu pairs %lld queries/bucket: median %u p90 %u p99 %u p999 %u max %u\n",
                 (long long)nl, touched, (long long)pairs, srt[srt.size() / 2], srt[srt.size() * 9 / 10],
                 srt[srt.size() * 99 / 100], srt[srt.size() * 999 / 1000], srt.back());
@@ -636,16 +662,36 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     lp.slack = ix->cfg.metric == DPF_METRIC_DOT ? ix->ws_slack.as<float>() : nullptr;
     lp.k = k;
     lp.delta = (float)((double)(ix->dpad + 8) * std::ldexp(1.0, -23));
-    { const char *e = getenv("DPF_LEAFSCAN"); lp.engine = (e && !strcmp(e, "valu")) ? 0 : ((e && !strcmp(e, "f32")) || ix->ks16 < 0 ? 1 : 2); }
+    lp.engine = engine;
     lp.ks = ix->ks16; lp.base16 = ix->d_base16.as<uint16_t>(); lp.Q16 = nullptr;
     if (lp.engine == 2) {
         HIPCHECK(ix, ix->ws_q16.ensure((size_t)nq * ix->ks16 * 32 * 2));
-        launch_rows_to_bf16((const float *)qpad, ix->dpad, ix->cfg.dim, nq, ix->ws_q16.as<uint16_t>(), ix->ks16 * 32, stream);
+        HIPCHECK(ix, ix->ws_q16n.ensure((size_t)nq * 4));
+        HIPCHECK(ix, ix->ws_q16e.ensure((size_t)nq * 4));
+        launch_rows_to_f16((const float *)qpad, ix->dpad, ix->cfg.dim, nq, ix->ws_q16.as<uint16_t>(), ix->ks16 * 32,
+                            ix->ws_q16n.as<float>(), ix->ws_q16e.as<float>(), stream);
+        lp.q16_norm = ix->ws_q16n.as<float>(); lp.q16_err = ix->ws_q16e.as<float>(); lp.base16_norm = ix->d_base16n.as<float>();
         lp.Q16 = ix->ws_q16.as<uint16_t>();
+        HIPCHECK(ix, ix->ws_units.ensure((size_t)std::max<int64_t>(nunits, 1) * 16));
+        launch_units(ix->ws_lq_cnt.as<uint32_t>(), ix->ws_lq_off.as<int64_t>(), ix->d_leaf_tile0.as<uint32_t>(),
+                     (const uint4 *)ix->d_tiles.p, nl, d_unit_cursor, (uint4 *)ix->ws_units.p, stream);
+        lp.units = (const uint4 *)ix->ws_units.p; lp.unit_begin = 0; lp.unit_end = nunits; lp.num_cus = ix->num_cus;
+        HIPCHECK(ix, ix->ws_emit_v.ensure((size_t)nq * EMIT_CAP * 4));
+        lp.emit_v = ix->ws_emit_v.as<float>();
     }
     lp.debug = getenv("DPF_LS_DEBUG") ? atoi(getenv("DPF_LS_DEBUG")) : 0;
     lp.emit = ix->ws_emit.as<int32_t>(); lp.emit_cnt = ix->ws_emit_cnt.as<int32_t>(); lp.emit_cap = EMIT_CAP;
     HIPCHECK(ix, hipEventRecord(ix->ev_scan[0], stream));
+    if (engine == 2) {
+        // a first slice of the units, then thresholds refined from what it forwarded, then the rest
+        static const int first_permille = getenv("DPF_FIRST_PASS") ? atoi(getenv("DPF_FIRST_PASS")) : 100;
+        const int64_t n_first = std::min<int64_t>(nunits, nunits * first_permille / 1000);
+        lp.unit_end = n_first;
+        launch_leafscan(ix->cfg.metric, (int)(ix->dpad / 4), lp, stream);
+        if (n_first > 0)
+            launch_refine(ix->cfg.metric, lp.emit, lp.emit_v, lp.emit_cnt, EMIT_CAP, k, nq, lp.q16_err, lp.tau, stream);
+        lp.unit_begin = n_first; lp.unit_end = nunits;
+    }
     launch_leafscan(ix->cfg.metric, (int)(ix->dpad / 4), lp, stream);
     HIPCHECK(ix, hipEventRecord(ix->ev_scan[1], stream));
     launch_overflow_flag(ix->ws_emit_cnt.as<int32_t>(), nq, EMIT_CAP, ix->ws_flag.as<int32_t>(), stream);

@@ -84,9 +84,16 @@ struct LeafScanParams {
     int32_t *emit_cnt;           // [nq] may exceed emit_cap: overflow
     int32_t emit_cap;
     int32_t debug;               // ablation switch for measurements (0 in production)
-    int32_t engine;              // 0 = vector ALU (lane per row), 1 = f32 MFMA 16x16x4, 2 = bf16 MFMA 16x16x32
-    const uint16_t *Q16;         // bf16 copies (engine 2): queries [nq][ks*32], rows [rows][ks*32]
+    int32_t engine;              // 0 = vector ALU (lane per row), 1 = f32 MFMA 16x16x4, 2 = fp16 MFMA 16x16x32
+    const uint16_t *Q16;         // fp16 copies (engine 2): queries [nq][ks*32], rows [rows][ks*32]
     const uint16_t *base16;
+    const float *q16_norm;       // [nq] / [rows] squared norms of the fp16 copies (fp32 sums)
+    const float *base16_norm;
+    const float *q16_err;        // [nq] upper bounds of |q - q~|
+    const uint4 *units;          // work units of the batch (engine 2), see k_units
+    int64_t unit_begin, unit_end; // the slice of units[] this launch works through
+    float *emit_v;               // [nq][emit_cap] pessimistic score bound of each forwarded row (engine 2)
+    int32_t num_cus;
     int32_t ks;
 };
 
@@ -112,9 +119,16 @@ size_t hash_shmem_bytes(const HashParams &p);
 void launch_probe(int mode, const ProbeParams &p, int64_t nq, hipStream_t stream);
 void launch_leafscan(int metric, int chunks16, const LeafScanParams &p, hipStream_t stream);
 int leafscan_padded_chunks(int nc);
-int leafscan_bf16_steps(int dim);
-void launch_rows_to_bf16(const float *src, int64_t src_stride, int dim, int64_t n, uint16_t *dst, int dst_stride,
-                         hipStream_t stream);
+void launch_unit_count(const uint32_t *lq_cnt, const uint32_t *leaf_tile0, int64_t nl, unsigned long long *total, hipStream_t stream);
+void launch_units(const uint32_t *lq_cnt, const int64_t *lq_off, const uint32_t *leaf_tile0, const uint4 *tiles, int64_t nl,
+                  unsigned long long *cursor, uint4 *units, hipStream_t stream);
+void launch_tile_maxnorm(uint4 *tiles, int64_t ntiles, const int32_t *ids, const float *norms, const float *errs, int64_t row_begin,
+                         int64_t row_end, hipStream_t stream);
+int leafscan_f16_steps(int dim);
+void launch_refine(int metric, const int32_t *emit, const float *emit_v, const int32_t *emit_cnt, int32_t cap, int k, int64_t nq,
+                   const float *q16_err, int32_t *tau, hipStream_t stream);
+void launch_rows_to_f16(const float *src, int64_t src_stride, int dim, int64_t n, uint16_t *dst, int dst_stride,
+                         float *norms, float *errs, hipStream_t stream);
 void launch_tau(int metric, const double *seed_scores, const int32_t *seed_ids, int k, int64_t nq, float delta,
                 float maxnorm, const float *qnorm, int32_t *tau, float *slack, hipStream_t stream);
 void launch_qnorm(const float *Q, int64_t q_stride, int64_t nq, float *out, hipStream_t stream);

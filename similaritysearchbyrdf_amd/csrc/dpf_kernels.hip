@@ -29,8 +29,8 @@
 
 #pragma clang fp contract(off)
 
-#ifndef LS16_WAVES
-#define LS16_WAVES 3
+#ifndef LS16_WAVES4
+#define LS16_WAVES4 2
 #endif
 #ifndef LEAFSCAN_WAVES
 #define LEAFSCAN_WAVES 4
@@ -1106,131 +1106,237 @@ static void launch_leafscan_mfma_m(int nc, const LeafScanParams &p, hipStream_t 
 }
 
 // ---------------------------------------------------------------------------
-// k_leafscan_bf16: the bucket-major filter on a bf16 copy of the rows
+// k_leafscan_f16: the bucket-major filter on an fp16 copy of the rows
 // ---------------------------------------------------------------------------
-// Same tiling as k_leafscan_mfma, but both operands are bf16 (rows padded to
-// KS*32 dimensions, 64*KS bytes, never straddling a 128-byte line) and the
-// products run on v_mfma_f32_16x16x32_bf16: half the HBM bytes per row and 1/7
-// of the matrix-core cycles.  The filter stays exact-safe because the
-// quantisation is bounded: |x~ - x| <= 2^-9 |x| for round-to-nearest bf16, so
-// | |q~ - x~| - |q - x| | <= 2^-9 (|q| + |x|) =: eta, and a candidate is
-// forwarded whenever its bf16 distance could still be within the threshold,
-//     s - slack32 <= (sqrt(tau) + eta)^2 .
+// Same 64-row x 16-query tiling as k_leafscan_mfma, but both operands are fp16
+// (rows padded to KS*32 dimensions, 64*KS bytes, never straddling a 128-byte line)
+// and the products run on v_mfma_f32_16x16x32_f16: half the HBM bytes per row and
+// 1/7 of the matrix-core cycles.  The filter stays exact-safe because the rounding
+// is MEASURED, not assumed: the conversion kernel stores |x - x~| per row (and per
+// query), so by the triangle inequality
+//     | |q~ - x~| - |q - x| | <= |q - q~| + |x - x~| =: eta,
+// and a candidate is forwarded whenever its fp16 distance could still be within the
+// threshold,   s - slack32 <= (sqrt(tau) + eta)^2 .
 // What is forwarded is rescored in fp64 from the fp32 rows.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-__device__ inline float bf16_sumsq(const bf16x8 &v)
+// Work units of one batch.  A unit is one 64-row tile of a touched bucket against at most
+// UNIT_QUERIES of the queries that probe the bucket: {first id slot, rows | queries << 8, first
+// slot in leaf_queries[], the tile's largest |x~| and |x - x~| as two 16-bit halves}.  The tile's rows are loaded once per
+// unit and scored against the queries 16 at a time; buckets probed by very many queries become
+// several units per tile, so no unit is long and a static interleave over the persistent waves
+// balances the chip.
+static constexpr uint32_t UNIT_QUERIES = 128;
+__device__ inline uint32_t units_of_leaf(uint32_t cnt, uint32_t ntl) { return cnt ? ntl * ((cnt + UNIT_QUERIES - 1u) / UNIT_QUERIES) : 0u; }
+
+__global__ __launch_bounds__(256) void k_unit_count(const uint32_t *__restrict__ lq_cnt, const uint32_t *__restrict__ leaf_tile0,
+                                                    int64_t nl, unsigned long long *__restrict__ total)
 {
-    float s = 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; e++) { const float f = (float)v[e]; s = fmaf(f, f, s); }
-    return s;
+    const int64_t l = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    unsigned long long n = 0;
+    if (l < nl) n = units_of_leaf(lq_cnt[l], leaf_tile0[l + 1] - leaf_tile0[l]);
+    for (int o = 32; o; o >>= 1) n += __shfl_down(n, o);
+    if ((threadIdx.x & 63) == 0 && n) atomicAdd(total, n);
 }
 
+__global__ __launch_bounds__(256) void k_units(const uint32_t *__restrict__ lq_cnt, const int64_t *__restrict__ lq_off,
+                                               const uint32_t *__restrict__ leaf_tile0, const uint4 *__restrict__ tiles,
+                                               int64_t nl, unsigned long long *__restrict__ cursor, uint4 *__restrict__ units)
+{
+    const int64_t l = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    uint32_t cnt = 0, t0 = 0, ntl = 0;
+    if (l < nl) { cnt = lq_cnt[l]; t0 = leaf_tile0[l]; ntl = leaf_tile0[l + 1] - t0; }
+    const uint32_t n = units_of_leaf(cnt, ntl);
+    // one reservation per wave, a prefix sum inside it
+    uint32_t inc = n;
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(inc, o); if (lane >= o) inc += v; }
+    const uint32_t wave_total = __shfl(inc, 63);
+    if (wave_total == 0) return;
+    unsigned long long base = 0;
+    if (lane == 63) base = atomicAdd(cursor, (unsigned long long)wave_total);
+    base = __shfl(base, 63) + (inc - n);
+    if (n == 0) return;
+    const uint32_t lqb = (uint32_t)lq_off[l];
+    for (uint32_t t = 0; t < ntl; t++) {
+        const uint4 td = tiles[t0 + t];
+        for (uint32_t c = 0; c < cnt; c += UNIT_QUERIES)
+            units[base++] = make_uint4(td.y, td.z | (min(UNIT_QUERIES, cnt - c) << 8), lqb + c, td.w);
+    }
+}
+
+// a non-negative float rounded UP to 8 significant bits, as the upper half of a word
+__device__ inline uint32_t ceil16_bits(float f)
+{
+    uint32_t u = __float_as_uint(f);
+    if (u & 0xffffu) u = (u | 0xffffu) + 1u;
+    return u & 0xffff0000u;
+}
+
+// tiles[t].w = two upper bounds over the tile's resident rows, both rounded up to 8 significant bits:
+// the largest norm of the fp16 copies (upper half) and the largest rounding distance (lower half)
+__global__ __launch_bounds__(256) void k_tile_maxnorm(uint4 *__restrict__ tiles, int64_t ntiles, const int32_t *__restrict__ ids,
+                                                      const float *__restrict__ norms, const float *__restrict__ errs,
+                                                      int64_t row_begin, int64_t row_end)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= ntiles) return;
+    uint4 td = tiles[t];
+    float m = 0.f, e = 0.f;
+    for (uint32_t i = 0; i < td.z; i++) {
+        const int64_t id = ids[td.y + i];
+        if (id >= row_begin && id < row_end) { m = fmaxf(m, norms[id - row_begin]); e = fmaxf(e, errs[id - row_begin]); }
+    }
+    td.w = ceil16_bits(sqrtf(m) * 1.00001f) | (ceil16_bits(e) >> 16);
+    tiles[t] = td;
+}
+
+void launch_unit_count(const uint32_t *lq_cnt, const uint32_t *leaf_tile0, int64_t nl, unsigned long long *total, hipStream_t stream)
+{
+    if (nl > 0) hipLaunchKernelGGL(k_unit_count, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, stream, lq_cnt, leaf_tile0, nl, total);
+}
+void launch_units(const uint32_t *lq_cnt, const int64_t *lq_off, const uint32_t *leaf_tile0, const uint4 *tiles, int64_t nl,
+                  unsigned long long *cursor, uint4 *units, hipStream_t stream)
+{
+    if (nl > 0) hipLaunchKernelGGL(k_units, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, stream, lq_cnt, lq_off, leaf_tile0, tiles, nl, cursor, units);
+}
+void launch_tile_maxnorm(uint4 *tiles, int64_t ntiles, const int32_t *ids, const float *norms, const float *errs, int64_t row_begin,
+                         int64_t row_end, hipStream_t stream)
+{
+    if (ntiles > 0) hipLaunchKernelGGL(k_tile_maxnorm, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, stream, tiles, ntiles, ids, norms, errs, row_begin, row_end);
+}
+
+// Persistent waves; wave w takes units w, w + W, w + 2W, ...  A unit needs two dependent levels
+// of loads (descriptor -> ids / query indices -> rows / query rows), so descriptors run three
+// units ahead and ids two, query indices one 16-query chunk ahead, and the rows and query rows
+// of the next step are requested as soon as the matrix cores have consumed the current ones:
+// their latency overlaps the threshold tests.
+// waves per SIMD the register budget is cut for: rows of 8 steps need 128 registers for the tile alone
+constexpr int ls16_waves(int ks) { return ks >= 8 ? 2 : (ks >= 4 ? LS16_WAVES4 : 3); }
+
 template <int KS, int METRIC>
-__global__ __launch_bounds__(256, LS16_WAVES) void k_leafscan_bf16(LeafScanParams p, const uint16_t *__restrict__ Q16,
+__global__ __launch_bounds__(256, ls16_waves(KS)) void k_leafscan_f16(LeafScanParams p, const uint16_t *__restrict__ Q16,
                                                                    const uint16_t *__restrict__ B16)
 {
     __shared__ int32_t s_fq[4][128], s_fid[4][128];
+    __shared__ float s_fv[4][128];                        // pessimistic bound of the forwarded row's exact score
     __shared__ float4 s_slot[4][16];                      // per query slot: {G, G2, bits of query index, bits of query id}
-    __shared__ float2 s_slot2[4][16];                     // {|q~|^2, 2^-9 |q| bound}
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
-    if (tile >= p.ntiles) return;
-    const uint4 td = p.tiles[tile];                      // {bucket, first id slot, rows, -}
-    const uint32_t leaf = td.x;
-    const int64_t lqb = p.lq_off[leaf], lqe = p.lq_off[leaf + 1];
-    if (lqb == lqe) return;
+    __shared__ float2 s_slot2[4][16];                     // {|q~|^2, l2: |q - q~|, dot: the slot's slack}
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t W = gridDim.x * 4u, nunits = (uint32_t)p.unit_end;
+    uint32_t u = (uint32_t)p.unit_begin + blockIdx.x * 4u + (uint32_t)wave;
+    if (u >= nunits) return;
     const int i16 = lane & 15, g = lane >> 4;
-    constexpr int STRIDE = KS * 32;                       // bf16 elements per padded row
+    constexpr int STRIDE = KS * 32;                       // fp16 elements per padded row
     const unsigned long long lt = (1ull << lane) - 1ull;
     const unsigned long long gmask = 0xffffull << (16 * g);
     // fp32 accumulation of the products and of the norms plus the roundings of the threshold
     // arithmetic below, per unit of |q~|^2 + |x~|^2
     const float c32 = (3.0f * (float)(STRIDE + 8) + 24.0f) * 5.9604645e-8f;
-    const float cq = 0.001953125f * 1.002f;                          // 2^-9 with room for the rounded norms
+    const int32_t row_lo = (int32_t)p.row_begin, row_hi = (int32_t)p.row_end;
 
     int nbuf = 0;
     auto flush = [&](int n) {
         if (lane < n) {
             const int32_t fq = s_fq[wave][lane];
             const int at = atomicAdd(&p.emit_cnt[fq], 1);
-            if (at < p.emit_cap) p.emit[(size_t)fq * p.emit_cap + at] = s_fid[wave][lane];
+            if (at < p.emit_cap) {
+                p.emit[(size_t)fq * p.emit_cap + at] = s_fid[wave][lane];
+                p.emit_v[(size_t)fq * p.emit_cap + at] = s_fv[wave][lane];
+            }
         }
     };
-
-    bf16x8 xb[4][KS];
-    int32_t idj[4];
-    float xn[4], J[4];                                    // |x~|^2; the row's share of the threshold
-    float xnm = 0.f;
+    auto desc = [&](uint32_t uu) { return uu < nunits ? p.units[uu] : make_uint4(0u, 0u, 0u, 0u); };
+    auto small = [&](const uint4 &U, int32_t (&id)[4], int32_t &qs, int32_t &qsn) {
+        const uint32_t rows = U.y & 0xffu, nq = U.y >> 8;
 #pragma unroll
-    for (int rb = 0; rb < 4; rb++) {
-        const uint32_t idx = rb * 16 + i16;
-        int32_t id = idx < td.z ? p.ids[td.y + idx] : -1;
-        if (!(id >= p.row_begin && id < p.row_end)) id = -1;
-        idj[rb] = id;
-        const uint16_t *row = B16 + (size_t)(id >= 0 ? id - p.row_begin : 0) * STRIDE + 8 * g;
-        float s = 0.f;
-#pragma unroll
-        for (int t = 0; t < KS; t++) {
-            xb[rb][t] = *(const bf16x8 *)(row + 32 * t);
-            s += bf16_sumsq(xb[rb][t]);
+        for (int rb = 0; rb < 4; rb++) {
+            const uint32_t idx = rb * 16 + i16;
+            int32_t v = idx < rows ? p.ids[U.x + idx] : -1;
+            if (!(v >= row_lo && v < row_hi)) v = -1;
+            id[rb] = v;
         }
-        s += __shfl_xor(s, 16);
-        s += __shfl_xor(s, 32);
-        xn[rb] = s;
-        // an absent row never reaches any threshold
-        J[rb] = id >= 0 ? (METRIC == 1 ? 0.5f * s * (1.0f - c32) : 0.f) : HUGE_VALF;
-        if (id >= 0) xnm = fmaxf(xnm, s);
-    }
-    for (int o = 1; o < 16; o <<= 1) xnm = fmaxf(xnm, __shfl_xor(xnm, o));   // bits 16 and 32 only permute equal copies
-    const float xrm = sqrtf(xnm) * 1.004f;               // upper bound of the largest |x| of the tile
-    const float cxm = cq * xrm;
+        qs = (uint32_t)i16 < nq ? p.leaf_queries[U.z + i16] : -1;
+        qsn = 16u + i16 < nq ? p.leaf_queries[U.z + 16u + i16] : -1;
+    };
 
-    int32_t qs_next = (lqb + i16 < lqe) ? p.leaf_queries[lqb + i16] : -1;
-    for (int64_t q0 = lqb; q0 < lqe; q0 += 16) {
-        const int32_t qs = qs_next;
-        if (q0 + 16 < lqe) qs_next = (q0 + 16 + i16 < lqe) ? p.leaf_queries[q0 + 16 + i16] : -1;
-        bf16x8 qa[KS];
-        float qn_slot = 0.f;
-        {
-            const uint16_t *qrow = Q16 + (size_t)(qs >= 0 ? qs : 0) * STRIDE + 8 * g;
+    f16x8 xb[4][KS], qa[KS];
+    float xn[4], m_tau, m_qn, m_qe;
+    int32_t m_qid;
+    auto load_rows = [&](const int32_t (&id)[4]) {
+        if (p.debug == 3) return;
 #pragma unroll
-            for (int t = 0; t < KS; t++) {
-                qa[t] = *(const bf16x8 *)(qrow + 32 * t);
-                qn_slot += bf16_sumsq(qa[t]);
-            }
-            qn_slot += __shfl_xor(qn_slot, 16);
-            qn_slot += __shfl_xor(qn_slot, 32);
+        for (int rb = 0; rb < 4; rb++) {
+            const size_t at = (size_t)(id[rb] >= 0 ? id[rb] - row_lo : 0);
+            const uint16_t *row = B16 + at * STRIDE + 8 * g;
+#pragma unroll
+            for (int t = 0; t < KS; t++) xb[rb][t] = *(const f16x8 *)(row + 32 * t);
+            xn[rb] = p.base16_norm[at];
         }
-        // Per-slot thresholds on d = q~.x~ - J(row), computed once by the slot's lane.
-        //   l2:  forward when |q~ - x~|^2 could be <= (sqrt(tau) + eta)^2, eta <= 2^-9 (|q| + |x|max):
+    };
+    auto load_queries = [&](int32_t qs) {
+        if (p.debug == 2) return;
+        const size_t qat = (size_t)(qs >= 0 ? qs : 0);
+        const uint16_t *qrow = Q16 + qat * STRIDE + 8 * g;
+#pragma unroll
+        for (int t = 0; t < KS; t++) qa[t] = *(const f16x8 *)(qrow + 32 * t);
+        m_tau = dec_f32(__hip_atomic_load(&p.tau[qat], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        m_qn = p.q16_norm[qat];
+        m_qe = p.q16_err[qat];
+        m_qid = p.qids ? p.qids[qat] : -1;
+    };
+
+    uint4 U0 = desc(u), U1 = desc(u + W), U2 = desc(u + 2u * W);
+    int32_t id0[4], id1[4], qs0, qs0n, qs1, qs1n;
+    small(U0, id0, qs0, qs0n);
+    small(U1, id1, qs1, qs1n);
+    load_rows(id0);
+    load_queries(qs0);
+    uint32_t chunk = 0;                                   // 16-query chunk of U0 in flight
+
+    for (;;) {
+        // Per-slot thresholds on d = q~.x~ - J(row); lane i16 of every 16-lane group holds query slot i16.
+        //   l2:  | |q~ - x~| - |q - x| | <= |q - q~| + |x - x~| =: eta, so forward when |q~ - x~|^2 could be
+        //        <= (sqrt(tau) + eta)^2 with the tile's largest |x - x~|:
         //        q~.x~ - |x~|^2/2 >= (|q~|^2 - (sqrt(tau) + eta)^2) / 2 =: G, rounding taken on the safe side
-        //   dot: forward when q~.x~ + 2^-8 |q||x|max >= tau
+        //   dot: |q.x - q~.x~| <= |q - q~||x~| + |q||x - x~|, so forward when q~.x~ + that slack >= tau
         // G2 is the level at which a row is roughly inside 0.985 sqrt(tau); it only triggers the
         // exact selection below, so it needs no rigour.
-        if (g == 0) {
-            float G = HUGE_VALF, G2 = HUGE_VALF, cqr = 0.f;
-            int32_t qid = -1;
-            if (qs >= 0) {
-                const float tau = dec_f32(__hip_atomic_load(&p.tau[qs], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                qid = p.qids ? p.qids[qs] : -1;
-                const float qr = sqrtf(qn_slot) * 1.004f;            // upper bound of |q|
-                cqr = cq * qr;
+        const float xrm = __uint_as_float(U0.w & 0xffff0000u);    // upper bound of the largest |x~| of the tile
+        const float cxm = __uint_as_float(U0.w << 16);            // upper bound of the largest |x - x~|
+        float dslack = 0.f;
+        {
+            float G = HUGE_VALF, G2 = HUGE_VALF;
+            const float cqr = m_qe;
+            if (qs0 >= 0) {
+                const float qr = sqrtf(m_qn) * 1.00001f;             // upper bound of |q~|
                 if (METRIC == 1) {
-                    if (tau >= 0.f) {
-                        const float st = sqrtf(tau);
+                    if (m_tau >= 0.f) {
+                        const float st = sqrtf(m_tau);
                         const float hi = st + cqr + cxm;
-                        G = fmaxf(0.5f * (qn_slot * (1.0f - c32) - hi * hi * 1.000001f), -3.0e38f);
+                        G = fmaxf(0.5f * (m_qn * (1.0f - c32) - hi * hi * 1.000001f), -3.0e38f);
                         const float w = 0.985f * st - cqr - cxm;
-                        if (w > 0.f) G2 = fmaxf(0.5f * (qn_slot * (1.0f + c32) - w * w) + c32 * xnm, -3.0e38f);
+                        if (w > 0.f) G2 = fmaxf(0.5f * (m_qn * (1.0f + c32) - w * w) + c32 * xrm * xrm, -3.0e38f);
                     }
                 } else {
-                    G = fmaxf(tau - (0.00390625f * 1.01f + c32) * qr * xrm - 1e-30f, -3.0e38f);
+                    dslack = (cqr * xrm + (qr + cqr) * cxm + c32 * qr * xrm) * 1.00001f + 1e-30f;
+                    G = fmaxf(m_tau - dslack, -3.0e38f);
                 }
             }
-            s_slot[wave][i16] = make_float4(G, G2, __int_as_float(qs), __int_as_float(qid));
-            s_slot2[wave][i16] = make_float2(qn_slot, cqr);
+            if (g == 0) {
+                s_slot[wave][i16] = make_float4(G, G2, __int_as_float(qs0), __int_as_float(m_qid));
+                s_slot2[wave][i16] = make_float2(m_qn, METRIC == 1 ? cqr : dslack);
+            }
+        }
+        int32_t idj[4];
+        float J[4], xnc[4];                               // the row's share of the threshold; |x~|^2
+#pragma unroll
+        for (int rb = 0; rb < 4; rb++) {
+            idj[rb] = id0[rb];
+            xnc[rb] = xn[rb];
+            // an absent row never reaches any threshold
+            J[rb] = id0[rb] >= 0 ? (METRIC == 1 ? 0.5f * xn[rb] * (1.0f - c32) : 0.f) : HUGE_VALF;
         }
         f32x4 acc[4];
 #pragma unroll
@@ -1238,8 +1344,38 @@ __global__ __launch_bounds__(256, LS16_WAVES) void k_leafscan_bf16(LeafScanParam
 #pragma unroll
         for (int t = 0; t < KS; t++)
 #pragma unroll
-            for (int rb = 0; rb < 4; rb++) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[t], xb[rb][t], acc[rb], 0, 0, 0);
+            for (int rb = 0; rb < 4; rb++) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qa[t], xb[rb][t], acc[rb], 0, 0, 0);
         // lane l holds q~(4g + r) . x~(rb*16 + i16) in acc[rb][r]
+
+        // next step: the unit's next 16 queries, or the next unit (its rows and query rows go out
+        // now, the unit after it gets its ids)
+        bool more = true;
+        chunk += 16u;
+        if (chunk < (U0.y >> 8)) {
+            qs0 = qs0n;
+            load_queries(qs0);
+            qs0n = chunk + 16u + i16 < (U0.y >> 8) ? p.leaf_queries[U0.z + chunk + 16u + i16] : -1;
+        } else {
+            u += W;
+            more = u < nunits;
+            chunk = 0;
+            U0 = U1; U1 = U2;
+#pragma unroll
+            for (int rb = 0; rb < 4; rb++) id0[rb] = id1[rb];
+            qs0 = qs1; qs0n = qs1n;
+            if (more) {
+                load_rows(id0);
+                load_queries(qs0);
+                small(U1, id1, qs1, qs1n);
+                U2 = desc(u + 2u * W);
+            }
+        }
+
+        if (p.debug) {                                    // ablation runs: loads and products only
+            if (acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] == 12345.678f) nbuf = 1;
+            if (!more) break;
+            continue;
+        }
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int slot = 4 * g + r;
@@ -1257,6 +1393,7 @@ __global__ __launch_bounds__(256, LS16_WAVES) void k_leafscan_bf16(LeafScanParam
             }
             if (many) {
                 const int32_t qq = __float_as_int(sc.z), qidq = __float_as_int(sc.w);
+                const float2 s2 = s_slot2[wave][slot];
 #pragma unroll
                 for (int rb = 0; rb < 4; rb++) {
                     const bool fwd = pass[rb] && !self_excluded(idj[rb], qidq, p.exclude_self);
@@ -1266,14 +1403,23 @@ __global__ __launch_bounds__(256, LS16_WAVES) void k_leafscan_bf16(LeafScanParam
                             const int at = nbuf + __popcll(m & lt);
                             s_fq[wave][at] = qq;
                             s_fid[wave][at] = idj[rb];
+                            // l2: sqrt(exact distance) <= sqrt(s_hi) + |x - x~|max + |q - q~|, the query's share is
+                            // added by the reader; dot: exact product >= q~.x~ - slack
+                            if (METRIC == 1) {
+                                const float s_hi = fmaf(-2.0f, acc[rb][r], (s2.x + xnc[rb]) * (1.0f + c32));
+                                s_fv[wave][at] = sqrtf(fmaxf(s_hi, 0.f)) * 1.000001f + cxm;
+                            } else {
+                                s_fv[wave][at] = acc[rb][r] - s2.y * 1.000001f;
+                            }
                         }
                         nbuf += __popcll(m);
                         if (nbuf >= 64) {
                             flush(64);
                             const int rest = nbuf - 64;
                             int32_t tq2 = 0, ti2 = 0;
-                            if (lane < rest) { tq2 = s_fq[wave][64 + lane]; ti2 = s_fid[wave][64 + lane]; }
-                            if (lane < rest) { s_fq[wave][lane] = tq2; s_fid[wave][lane] = ti2; }
+                            float tv2 = 0.f;
+                            if (lane < rest) { tq2 = s_fq[wave][64 + lane]; ti2 = s_fid[wave][64 + lane]; tv2 = s_fv[wave][64 + lane]; }
+                            if (lane < rest) { s_fq[wave][lane] = tq2; s_fid[wave][lane] = ti2; s_fv[wave][lane] = tv2; }
                             nbuf = rest;
                         }
                     }
@@ -1281,7 +1427,7 @@ __global__ __launch_bounds__(256, LS16_WAVES) void k_leafscan_bf16(LeafScanParam
             }
             if (METRIC == 1 && tight >= p.k) {
                 // Roughly k or more rows of this tile sit inside 0.985 sqrt(tau).  With
-                //   v = sqrt(s_hi) + 2^-9 |x|max >= sqrt(exact distance) - 2^-9 |q|
+                //   v = sqrt(s_hi) + |x - x~|max >= sqrt(exact distance) - |q - q~|
                 // (s_hi = |q~ - x~|^2 rounded up), the k-th smallest v among the 64 rows this 16-lane
                 // group holds for the query bounds the query's k-th best distance from above.
                 const int32_t qq = __float_as_int(sc.z), qidq = __float_as_int(sc.w);
@@ -1290,7 +1436,7 @@ __global__ __launch_bounds__(256, LS16_WAVES) void k_leafscan_bf16(LeafScanParam
 #pragma unroll
                 for (int rb = 0; rb < 4; rb++) {
                     const bool ok = idj[rb] >= 0 && !self_excluded(idj[rb], qidq, p.exclude_self);
-                    const float s_hi = fmaf(-2.0f, acc[rb][r], (s2.x + xn[rb]) * (1.0f + c32));
+                    const float s_hi = fmaf(-2.0f, acc[rb][r], (s2.x + xnc[rb]) * (1.0f + c32));
                     v[rb] = ok ? sqrtf(fmaxf(s_hi, 0.f)) * 1.000001f + cxm : HUGE_VALF;
                 }
                 int rank[4] = {0, 0, 0, 0};
@@ -1313,15 +1459,19 @@ __global__ __launch_bounds__(256, LS16_WAVES) void k_leafscan_bf16(LeafScanParam
                 }
             }
         }
+        if (!more) break;
     }
     flush(nbuf);
 }
 
 template <int METRIC>
-static void launch_leafscan_bf16_m(const LeafScanParams &p, hipStream_t stream)
+static void launch_leafscan_f16_m(const LeafScanParams &p, hipStream_t stream)
 {
-    dim3 grid((unsigned)((p.ntiles + 3) / 4)), block(256);
-#define DPF_LB(KS) hipLaunchKernelGGL((k_leafscan_bf16<KS, METRIC>), grid, block, 0, stream, p, p.Q16, p.base16)
+    const int64_t n = p.unit_end - p.unit_begin;
+    if (n <= 0) return;
+    const int64_t resident = (int64_t)p.num_cus * ls16_waves(p.ks);       // workgroups the chip holds at once
+    dim3 grid((unsigned)std::min<int64_t>((n + 3) / 4, resident)), block(256);
+#define DPF_LB(KS) hipLaunchKernelGGL((k_leafscan_f16<KS, METRIC>), grid, block, 0, stream, p, p.Q16, p.base16)
     switch (p.ks) {
     case 1: DPF_LB(1); break;
     case 2: DPF_LB(2); break;
@@ -1331,8 +1481,65 @@ static void launch_leafscan_bf16_m(const LeafScanParams &p, hipStream_t stream)
 #undef DPF_LB
 }
 
-// bf16 steps (of 32 dimensions) a padded row takes: 1, 2, 4 or 8; -1 when the row is too long
-int leafscan_bf16_steps(int dim)
+// k_refine: between two passes of the scan, tighten each query's threshold from what the first
+// pass forwarded.  The k-th best of the pessimistic bounds of k DISTINCT rows bounds the query's
+// k-th best exact score; one wave per query keeps the k best (bound, id) sorted across its lanes.
+template <int METRIC>
+__global__ __launch_bounds__(256) void k_refine(const int32_t *__restrict__ emit, const float *__restrict__ emit_v,
+                                                const int32_t *__restrict__ emit_cnt, int32_t cap, int k, int64_t nq,
+                                                const float *__restrict__ q16_err, int32_t *__restrict__ tau)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    const int n = min(emit_cnt[q], cap);
+    if (n < k) return;
+    float ls = METRIC == 1 ? HUGE_VALF : -HUGE_VALF;
+    int32_t lid = -1;
+    for (int base = 0; base < n; base += 64) {
+        const bool live = base + lane < n;
+        const float v = live ? emit_v[(size_t)q * cap + base + lane] : 0.f;
+        const int32_t id = live ? emit[(size_t)q * cap + base + lane] : -1;
+        const float kth = __shfl(ls, k - 1);
+        unsigned long long m = __ballot(live && (METRIC == 1 ? v < kth : v > kth));
+        while (m) {
+            const int src = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const float s = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+            const int32_t sid = __builtin_amdgcn_readlane(id, src);
+            // one entry per row: a row forwarded from two buckets keeps its first bound
+            if (__ballot(lane < k && lid == sid)) continue;
+            const bool shift = lane < k && (METRIC == 1 ? s < ls : s > ls);
+            const unsigned long long mask = __ballot(shift);
+            if (mask == 0) continue;
+            const int pos = __ffsll((long long)mask) - 1;
+            const float ps = __shfl_up(ls, 1);
+            const int32_t pid = __shfl_up(lid, 1);
+            if (lane == pos) { ls = s; lid = sid; }
+            else if (lane > pos && lane < k) { ls = ps; lid = pid; }
+        }
+    }
+    if (lane == k - 1 && lid >= 0) {
+        if (METRIC == 1) {
+            const float b = (ls + q16_err[q]) * 1.000001f;
+            atomicMin(&tau[q], enc_f32(b * b * 1.000001f));
+        } else {
+            atomicMax(&tau[q], enc_f32(ls));
+        }
+    }
+}
+
+void launch_refine(int metric, const int32_t *emit, const float *emit_v, const int32_t *emit_cnt, int32_t cap, int k, int64_t nq,
+                   const float *q16_err, int32_t *tau, hipStream_t stream)
+{
+    if (nq <= 0) return;
+    dim3 grid((unsigned)((nq + 3) / 4)), block(256);
+    if (metric == 0) hipLaunchKernelGGL((k_refine<0>), grid, block, 0, stream, emit, emit_v, emit_cnt, cap, k, nq, q16_err, tau);
+    else hipLaunchKernelGGL((k_refine<1>), grid, block, 0, stream, emit, emit_v, emit_cnt, cap, k, nq, q16_err, tau);
+}
+
+// fp16 steps (of 32 dimensions) a padded row takes: 1, 2, 4 or 8; -1 when the row is too long
+int leafscan_f16_steps(int dim)
 {
     const int ks = (dim + 31) / 32;
     if (ks <= 1) return 1;
@@ -1341,31 +1548,53 @@ int leafscan_bf16_steps(int dim)
     return ks <= 8 ? 8 : -1;
 }
 
-// fp32 rows (stride src_stride floats, `dim` meaningful) -> bf16 rows of dst_stride elements,
-// round to nearest even, zero padded
-__global__ void k_rows_to_bf16(const float *__restrict__ src, int64_t src_stride, int dim, int64_t n,
-                               uint16_t *__restrict__ dst, int dst_stride)
+// fp32 rows (stride src_stride floats, `dim` meaningful) -> fp16 rows of dst_stride elements (a
+// multiple of 32), round to nearest even, zero padded; norms[r] = sum of the squares of the ROUNDED
+// elements of row r, accumulated in fp32; errs[r] = an upper bound of |row - rounded row| (the
+// element differences are exact in fp32).  One lane converts 8 consecutive elements.
+__global__ void k_rows_to_f16(const float *__restrict__ src, int64_t src_stride, int dim, int64_t n,
+                               uint16_t *__restrict__ dst, int dst_stride, float *__restrict__ norms, float *__restrict__ errs)
 {
-    const int64_t total = n * dst_stride;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = i / dst_stride;
-        const int c = (int)(i - r * dst_stride);
-        uint16_t o = 0;
-        if (c < dim) {
-            const uint32_t u = __float_as_uint(src[r * src_stride + c]);
-            o = (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+    const int per_row = dst_stride >> 3;                  // lanes per row: 4, 8, 16 or 32
+    const int64_t total = n * per_row;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i < total;
+    const int64_t r = live ? i / per_row : 0;
+    const int c0 = (int)(i - r * per_row) * 8;
+    uint16_t o[8];
+    float ss = 0.f, ee = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        o[e] = 0;
+        if (live && c0 + e < dim) {
+            const float x = src[r * src_stride + c0 + e];
+            // nearest fp16, clamped to the finite range; what would be subnormal becomes 0 so that
+            // the matrix cores see exactly the values the norms and distances are taken from
+            _Float16 h = (_Float16)fminf(fmaxf(x, -65504.0f), 65504.0f);
+            if (fabsf((float)h) < 6.103515625e-5f) h = (_Float16)0.0f;
+            o[e] = __builtin_bit_cast(uint16_t, h);
+            const float f = (float)h;
+            ss = fmaf(f, f, ss);
+            const float df = x - f;
+            ee = fmaf(df, df, ee);
         }
-        dst[i] = o;
     }
+    if (live) {
+        uint4 w;
+        w.x = o[0] | ((uint32_t)o[1] << 16); w.y = o[2] | ((uint32_t)o[3] << 16);
+        w.z = o[4] | ((uint32_t)o[5] << 16); w.w = o[6] | ((uint32_t)o[7] << 16);
+        *(uint4 *)(dst + i * 8) = w;
+    }
+    for (int m = 1; m < per_row; m <<= 1) { ss += __shfl_xor(ss, m); ee += __shfl_xor(ee, m); }   // rows never straddle a wave
+    if (live && c0 == 0) { norms[r] = ss; errs[r] = sqrtf(ee * 1.0001f) * 1.00001f; }
 }
-
-void launch_rows_to_bf16(const float *src, int64_t src_stride, int dim, int64_t n, uint16_t *dst, int dst_stride,
-                         hipStream_t stream)
+void launch_rows_to_f16(const float *src, int64_t src_stride, int dim, int64_t n, uint16_t *dst, int dst_stride,
+                         float *norms, float *errs, hipStream_t stream)
 {
     if (n <= 0) return;
-    const int64_t total = n * dst_stride;
-    unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 65535 * 8);
-    hipLaunchKernelGGL(k_rows_to_bf16, dim3(grid), dim3(256), 0, stream, src, src_stride, dim, n, dst, dst_stride);
+    const int64_t total = n * (dst_stride / 8);
+    hipLaunchKernelGGL(k_rows_to_f16, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, src, src_stride, dim, n,
+                       dst, dst_stride, norms, errs);
 }
 
 // Filter thresholds on the fp32 score, from the exact k-th best of each query's seed sample.
@@ -1432,8 +1661,8 @@ void launch_leafscan(int metric, int chunks16, const LeafScanParams &p, hipStrea
 {
     if (p.ntiles <= 0) return;
     if (p.engine == 2) {
-        if (metric == 0) launch_leafscan_bf16_m<0>(p, stream);
-        else launch_leafscan_bf16_m<1>(p, stream);
+        if (metric == 0) launch_leafscan_f16_m<0>(p, stream);
+        else launch_leafscan_f16_m<1>(p, stream);
         return;
     }
     if (p.engine == 1) {
