@@ -69,7 +69,7 @@ struct dpf_index {
     DevBuf d_base16n, ws_q16n;               // their squared norms
     DevBuf d_base16, ws_q16;                 // fp16 copies of the resident rows / of the query batch
     int ks16 = -1;                           // 32-dimension fp16 steps per padded row (-1: no fp16 scan)
-    int64_t ntiles = 0, num_leaves = 0;
+    int64_t ntiles = 0, nutiles = 0, num_leaves = 0;
     std::vector<uint32_t> h_leaf_len;        // rows per bucket of the uploaded snapshot
     double maxnorm = 0.0;                    // largest base-row norm seen by dpf_fit
     bool bucket_major = false;               // the bucket-major rerank applies to this handle
@@ -330,16 +330,20 @@ static int upload_snapshot(dpf_index *ix, ForestSnapshot &s)
         s.leaf_off.swap(off);
     }
     std::vector<uint32_t> tile_leaf, tile_row0, tiles, leaf_tile0(s.leaf_off.size(), 0u);
+    const uint32_t TR = 64;                               // rows per work-unit tile of the fp16 scan
     for (size_t l = 0; l + 1 < s.leaf_off.size(); l++) {
         const uint32_t len = s.leaf_off[l + 1] - s.leaf_off[l];
-        leaf_tile0[l] = (uint32_t)tile_leaf.size();
-        for (uint32_t r = 0; r < len; r += 64) {
+        leaf_tile0[l] = (uint32_t)(tiles.size() / 4);
+        for (uint32_t r = 0; r < len; r += 64) {          // 64-row tiles of the fp32 engines
             tile_leaf.push_back((uint32_t)l);
             tile_row0.push_back(r);
-            tiles.push_back((uint32_t)l); tiles.push_back(s.leaf_off[l] + r); tiles.push_back(std::min<uint32_t>(64u, len - r)); tiles.push_back(0u);
+        }
+        for (uint32_t r = 0; r < len; r += TR) {          // work-unit tiles of the fp16 scan
+            tiles.push_back((uint32_t)l); tiles.push_back(s.leaf_off[l] + r); tiles.push_back(std::min<uint32_t>(TR, len - r)); tiles.push_back(0u);
         }
     }
-    leaf_tile0.back() = (uint32_t)tile_leaf.size();
+    leaf_tile0.back() = (uint32_t)(tiles.size() / 4);
+    ix->nutiles = (int64_t)(tiles.size() / 4);
     if ((rc = upload(ix, ix->d_tiles, tiles)) != DPF_OK) return rc;
     if ((rc = upload(ix, ix->d_leaf_tile0, leaf_tile0)) != DPF_OK) return rc;
     ix->h_leaf_len.resize(s.leaf_off.size() - 1);
@@ -358,7 +362,7 @@ static int upload_snapshot(dpf_index *ix, ForestSnapshot &s)
     ix->st.misflag_events = s.misflag_events;
     ix->st.snapshot_bytes = (int64_t)(s.roots.size() * 4 + s.dnodes.size() * 4 + s.leaf_off.size() * 4 + s.ids.size() * 4);
     if (ix->bucket_major && ix->ks16 > 0 && ix->ntiles > 0 && ix->base_rows > 0) {
-        launch_tile_maxnorm((uint4 *)ix->d_tiles.p, ix->ntiles, ix->d_ids.as<int32_t>(), ix->d_base16n.as<float>(), ix->d_base16e.as<float>(),
+        launch_tile_maxnorm((uint4 *)ix->d_tiles.p, ix->nutiles, ix->d_ids.as<int32_t>(), ix->d_base16n.as<float>(), ix->d_base16e.as<float>(),
                             ix->row_begin, ix->row_begin + ix->base_rows, nullptr);
         HIPCHECK(ix, hipDeviceSynchronize());
     }

@@ -1207,16 +1207,16 @@ void launch_tile_maxnorm(uint4 *tiles, int64_t ntiles, const int32_t *ids, const
 }
 
 // Persistent waves; wave w takes units w, w + W, w + 2W, ...  A unit needs two dependent levels
-// of loads (descriptor -> ids / query indices -> rows / query rows), so descriptors run three
-// units ahead and ids two, query indices one 16-query chunk ahead, and the rows and query rows
-// of the next step are requested as soon as the matrix cores have consumed the current ones:
-// their latency overlaps the threshold tests.
-// waves per SIMD the register budget is cut for: rows of 8 steps need 128 registers for the tile alone
-constexpr int ls16_waves(int ks) { return ks >= 8 ? 2 : (ks >= 4 ? LS16_WAVES4 : 3); }
+// of loads (descriptor -> ids / query indices -> rows / query rows): descriptors run two units
+// ahead and ids one, query indices one 16-query chunk ahead, so a wave waits once per unit (rows +
+// first queries) and once per further chunk; the other waves of the SIMD fill those waits.
+// RB*16 rows per tile: 64 measured best on gfx950 (32-row tiles double the per-unit work and
+// were 1.9x slower in spite of the higher occupancy).
+constexpr int ls16_waves(int ks, int rb) { return rb == 2 ? (ks >= 8 ? 2 : 4) : (ks >= 8 ? 2 : 3); }
 
-template <int KS, int METRIC>
-__global__ __launch_bounds__(256, ls16_waves(KS)) void k_leafscan_f16(LeafScanParams p, const uint16_t *__restrict__ Q16,
-                                                                   const uint16_t *__restrict__ B16)
+template <int KS, int METRIC, int RB>
+__global__ __launch_bounds__(256, ls16_waves(KS, RB)) void k_leafscan_f16(LeafScanParams p, const uint16_t *__restrict__ Q16,
+                                                                          const uint16_t *__restrict__ B16)
 {
     __shared__ int32_t s_fq[4][128], s_fid[4][128];
     __shared__ float s_fv[4][128];                        // pessimistic bound of the forwarded row's exact score
@@ -1248,10 +1248,10 @@ __global__ __launch_bounds__(256, ls16_waves(KS)) void k_leafscan_f16(LeafScanPa
         }
     };
     auto desc = [&](uint32_t uu) { return uu < nunits ? p.units[uu] : make_uint4(0u, 0u, 0u, 0u); };
-    auto small = [&](const uint4 &U, int32_t (&id)[4], int32_t &qs, int32_t &qsn) {
+    auto small = [&](const uint4 &U, int32_t (&id)[RB], int32_t &qs, int32_t &qsn) {
         const uint32_t rows = U.y & 0xffu, nq = U.y >> 8;
 #pragma unroll
-        for (int rb = 0; rb < 4; rb++) {
+        for (int rb = 0; rb < RB; rb++) {
             const uint32_t idx = rb * 16 + i16;
             int32_t v = idx < rows ? p.ids[U.x + idx] : -1;
             if (!(v >= row_lo && v < row_hi)) v = -1;
@@ -1261,217 +1261,195 @@ __global__ __launch_bounds__(256, ls16_waves(KS)) void k_leafscan_f16(LeafScanPa
         qsn = 16u + i16 < nq ? p.leaf_queries[U.z + 16u + i16] : -1;
     };
 
-    f16x8 xb[4][KS], qa[KS];
-    float xn[4], m_tau, m_qn, m_qe;
-    int32_t m_qid;
-    auto load_rows = [&](const int32_t (&id)[4]) {
-        if (p.debug == 3) return;
+    uint4 U0 = desc(u), U1 = desc(u + W);
+    int32_t id0[RB], qs0, qs0n;
+    small(U0, id0, qs0, qs0n);
+
+    for (; u < nunits; u += W) {
+        // this unit's rows
+        f16x8 xb[RB][KS];
+        float J[RB], xn[RB];                              // the row's share of the threshold; |x~|^2
 #pragma unroll
-        for (int rb = 0; rb < 4; rb++) {
-            const size_t at = (size_t)(id[rb] >= 0 ? id[rb] - row_lo : 0);
+        for (int rb = 0; rb < RB; rb++) {
+            const size_t at = (size_t)(id0[rb] >= 0 ? id0[rb] - row_lo : 0);
             const uint16_t *row = B16 + at * STRIDE + 8 * g;
 #pragma unroll
             for (int t = 0; t < KS; t++) xb[rb][t] = *(const f16x8 *)(row + 32 * t);
             xn[rb] = p.base16_norm[at];
         }
-    };
-    auto load_queries = [&](int32_t qs) {
-        if (p.debug == 2) return;
-        const size_t qat = (size_t)(qs >= 0 ? qs : 0);
-        const uint16_t *qrow = Q16 + qat * STRIDE + 8 * g;
+        int32_t idj[RB];
 #pragma unroll
-        for (int t = 0; t < KS; t++) qa[t] = *(const f16x8 *)(qrow + 32 * t);
-        m_tau = dec_f32(__hip_atomic_load(&p.tau[qat], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        m_qn = p.q16_norm[qat];
-        m_qe = p.q16_err[qat];
-        m_qid = p.qids ? p.qids[qat] : -1;
-    };
-
-    uint4 U0 = desc(u), U1 = desc(u + W), U2 = desc(u + 2u * W);
-    int32_t id0[4], id1[4], qs0, qs0n, qs1, qs1n;
-    small(U0, id0, qs0, qs0n);
-    small(U1, id1, qs1, qs1n);
-    load_rows(id0);
-    load_queries(qs0);
-    uint32_t chunk = 0;                                   // 16-query chunk of U0 in flight
-
-    for (;;) {
-        // Per-slot thresholds on d = q~.x~ - J(row); lane i16 of every 16-lane group holds query slot i16.
-        //   l2:  | |q~ - x~| - |q - x| | <= |q - q~| + |x - x~| =: eta, so forward when |q~ - x~|^2 could be
-        //        <= (sqrt(tau) + eta)^2 with the tile's largest |x - x~|:
-        //        q~.x~ - |x~|^2/2 >= (|q~|^2 - (sqrt(tau) + eta)^2) / 2 =: G, rounding taken on the safe side
-        //   dot: |q.x - q~.x~| <= |q - q~||x~| + |q||x - x~|, so forward when q~.x~ + that slack >= tau
-        // G2 is the level at which a row is roughly inside 0.985 sqrt(tau); it only triggers the
-        // exact selection below, so it needs no rigour.
+        for (int rb = 0; rb < RB; rb++) idj[rb] = id0[rb];
+        const uint32_t nq = U0.y >> 8, lq0 = U0.z;
         const float xrm = __uint_as_float(U0.w & 0xffff0000u);    // upper bound of the largest |x~| of the tile
         const float cxm = __uint_as_float(U0.w << 16);            // upper bound of the largest |x - x~|
-        float dslack = 0.f;
-        {
-            float G = HUGE_VALF, G2 = HUGE_VALF;
-            const float cqr = m_qe;
-            if (qs0 >= 0) {
-                const float qr = sqrtf(m_qn) * 1.00001f;             // upper bound of |q~|
-                if (METRIC == 1) {
-                    if (m_tau >= 0.f) {
-                        const float st = sqrtf(m_tau);
-                        const float hi = st + cqr + cxm;
-                        G = fmaxf(0.5f * (m_qn * (1.0f - c32) - hi * hi * 1.000001f), -3.0e38f);
-                        const float w = 0.985f * st - cqr - cxm;
-                        if (w > 0.f) G2 = fmaxf(0.5f * (m_qn * (1.0f + c32) - w * w) + c32 * xrm * xrm, -3.0e38f);
+        // the next unit's ids and first query indices, the descriptor after it
+        int32_t qsc = qs0, qsn = qs0n;
+        U0 = U1;
+        U1 = desc(u + 2u * W);
+        small(U0, id0, qs0, qs0n);
+#pragma unroll
+        for (int rb = 0; rb < RB; rb++)                   // an absent row never reaches any threshold
+            J[rb] = idj[rb] >= 0 ? (METRIC == 1 ? 0.5f * xn[rb] * (1.0f - c32) : 0.f) : HUGE_VALF;
+
+        for (uint32_t c = 0; c < nq; c += 16u) {
+            f16x8 qa[KS];
+            const size_t qat = (size_t)(qsc >= 0 ? qsc : 0);
+            {
+                const uint16_t *qrow = Q16 + qat * STRIDE + 8 * g;
+#pragma unroll
+                for (int t = 0; t < KS; t++) qa[t] = *(const f16x8 *)(qrow + 32 * t);
+            }
+            const float m_tau = dec_f32(__hip_atomic_load(&p.tau[qat], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            const float m_qn = p.q16_norm[qat], m_qe = p.q16_err[qat];
+            const int32_t m_qid = p.qids ? p.qids[qat] : -1;
+            const int32_t qcur = qsc;
+            // query indices two chunks ahead
+            qsc = qsn;
+            qsn = c + 32u + i16 < nq ? p.leaf_queries[lq0 + c + 32u + i16] : -1;
+
+            // Per-slot thresholds on d = q~.x~ - J(row); lane i16 of every 16-lane group holds query slot i16.
+            //   l2:  | |q~ - x~| - |q - x| | <= |q - q~| + |x - x~| =: eta, so forward when |q~ - x~|^2 could be
+            //        <= (sqrt(tau) + eta)^2 with the tile's largest |x - x~|:
+            //        q~.x~ - |x~|^2/2 >= (|q~|^2 - (sqrt(tau) + eta)^2) / 2 =: G, rounding taken on the safe side
+            //   dot: |q.x - q~.x~| <= |q - q~||x~| + |q||x - x~|, so forward when q~.x~ + that slack >= tau
+            // G2 is the level at which a row is roughly inside 0.985 sqrt(tau); it only triggers the
+            // exact selection below, so it needs no rigour.
+            {
+                float G = HUGE_VALF, G2 = HUGE_VALF, dslack = 0.f;
+                if (qcur >= 0) {
+                    const float qr = sqrtf(m_qn) * 1.00001f;         // upper bound of |q~|
+                    if (METRIC == 1) {
+                        if (m_tau >= 0.f) {
+                            const float st = sqrtf(m_tau);
+                            const float hi = st + m_qe + cxm;
+                            G = fmaxf(0.5f * (m_qn * (1.0f - c32) - hi * hi * 1.000001f), -3.0e38f);
+                            const float w = 0.985f * st - m_qe - cxm;
+                            if (w > 0.f) G2 = fmaxf(0.5f * (m_qn * (1.0f + c32) - w * w) + c32 * xrm * xrm, -3.0e38f);
+                        }
+                    } else {
+                        dslack = (m_qe * xrm + (qr + m_qe) * cxm + c32 * qr * xrm) * 1.00001f + 1e-30f;
+                        G = fmaxf(m_tau - dslack, -3.0e38f);
                     }
-                } else {
-                    dslack = (cqr * xrm + (qr + cqr) * cxm + c32 * qr * xrm) * 1.00001f + 1e-30f;
-                    G = fmaxf(m_tau - dslack, -3.0e38f);
+                }
+                if (g == 0) {
+                    s_slot[wave][i16] = make_float4(G, G2, __int_as_float(qcur), __int_as_float(m_qid));
+                    s_slot2[wave][i16] = make_float2(m_qn, METRIC == 1 ? m_qe : dslack);
                 }
             }
-            if (g == 0) {
-                s_slot[wave][i16] = make_float4(G, G2, __int_as_float(qs0), __int_as_float(m_qid));
-                s_slot2[wave][i16] = make_float2(m_qn, METRIC == 1 ? cqr : dslack);
+            f32x4 acc[RB];
+#pragma unroll
+            for (int rb = 0; rb < RB; rb++) acc[rb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < KS; t++)
+#pragma unroll
+                for (int rb = 0; rb < RB; rb++) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qa[t], xb[rb][t], acc[rb], 0, 0, 0);
+            // lane l holds q~(4g + r) . x~(rb*16 + i16) in acc[rb][r]
+            if (p.debug) {                                // ablation runs: loads and products only
+                float t = 0.f;
+#pragma unroll
+                for (int rb = 0; rb < RB; rb++) t += acc[rb][rb];
+                if (t == 12345.678f) nbuf = 1;
+                continue;
             }
-        }
-        int32_t idj[4];
-        float J[4], xnc[4];                               // the row's share of the threshold; |x~|^2
 #pragma unroll
-        for (int rb = 0; rb < 4; rb++) {
-            idj[rb] = id0[rb];
-            xnc[rb] = xn[rb];
-            // an absent row never reaches any threshold
-            J[rb] = id0[rb] >= 0 ? (METRIC == 1 ? 0.5f * xn[rb] * (1.0f - c32) : 0.f) : HUGE_VALF;
-        }
-        f32x4 acc[4];
+            for (int r = 0; r < 4; r++) {
+                const int slot = 4 * g + r;
+                const float4 sc = s_slot[wave][slot];
+                float d[RB];
+                bool pass[RB];
+                int tight = 0;
+                unsigned long long many = 0;
 #pragma unroll
-        for (int rb = 0; rb < 4; rb++) acc[rb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int rb = 0; rb < RB; rb++) {
+                    d[rb] = acc[rb][r] - J[rb];
+                    pass[rb] = d[rb] >= sc.x;
+                    many |= __ballot(pass[rb]);
+                    if (METRIC == 1) tight += __popcll(__ballot(d[rb] >= sc.y) & gmask);
+                }
+                if (many) {
+                    const int32_t qq = __float_as_int(sc.z), qidq = __float_as_int(sc.w);
+                    const float2 s2 = s_slot2[wave][slot];
 #pragma unroll
-        for (int t = 0; t < KS; t++)
-#pragma unroll
-            for (int rb = 0; rb < 4; rb++) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qa[t], xb[rb][t], acc[rb], 0, 0, 0);
-        // lane l holds q~(4g + r) . x~(rb*16 + i16) in acc[rb][r]
-
-        // next step: the unit's next 16 queries, or the next unit (its rows and query rows go out
-        // now, the unit after it gets its ids)
-        bool more = true;
-        chunk += 16u;
-        if (chunk < (U0.y >> 8)) {
-            qs0 = qs0n;
-            load_queries(qs0);
-            qs0n = chunk + 16u + i16 < (U0.y >> 8) ? p.leaf_queries[U0.z + chunk + 16u + i16] : -1;
-        } else {
-            u += W;
-            more = u < nunits;
-            chunk = 0;
-            U0 = U1; U1 = U2;
-#pragma unroll
-            for (int rb = 0; rb < 4; rb++) id0[rb] = id1[rb];
-            qs0 = qs1; qs0n = qs1n;
-            if (more) {
-                load_rows(id0);
-                load_queries(qs0);
-                small(U1, id1, qs1, qs1n);
-                U2 = desc(u + 2u * W);
-            }
-        }
-
-        if (p.debug) {                                    // ablation runs: loads and products only
-            if (acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] == 12345.678f) nbuf = 1;
-            if (!more) break;
-            continue;
-        }
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int slot = 4 * g + r;
-            const float4 sc = s_slot[wave][slot];
-            float d[4];
-            bool pass[4];
-            int tight = 0;
-            unsigned long long many = 0;
-#pragma unroll
-            for (int rb = 0; rb < 4; rb++) {
-                d[rb] = acc[rb][r] - J[rb];
-                pass[rb] = d[rb] >= sc.x;
-                many |= __ballot(pass[rb]);
-                if (METRIC == 1) tight += __popcll(__ballot(d[rb] >= sc.y) & gmask);
-            }
-            if (many) {
-                const int32_t qq = __float_as_int(sc.z), qidq = __float_as_int(sc.w);
-                const float2 s2 = s_slot2[wave][slot];
-#pragma unroll
-                for (int rb = 0; rb < 4; rb++) {
-                    const bool fwd = pass[rb] && !self_excluded(idj[rb], qidq, p.exclude_self);
-                    const unsigned long long m = __ballot(fwd);
-                    if (m) {
-                        if (fwd) {
-                            const int at = nbuf + __popcll(m & lt);
-                            s_fq[wave][at] = qq;
-                            s_fid[wave][at] = idj[rb];
-                            // l2: sqrt(exact distance) <= sqrt(s_hi) + |x - x~|max + |q - q~|, the query's share is
-                            // added by the reader; dot: exact product >= q~.x~ - slack
-                            if (METRIC == 1) {
-                                const float s_hi = fmaf(-2.0f, acc[rb][r], (s2.x + xnc[rb]) * (1.0f + c32));
-                                s_fv[wave][at] = sqrtf(fmaxf(s_hi, 0.f)) * 1.000001f + cxm;
-                            } else {
-                                s_fv[wave][at] = acc[rb][r] - s2.y * 1.000001f;
+                    for (int rb = 0; rb < RB; rb++) {
+                        const bool fwd = pass[rb] && !self_excluded(idj[rb], qidq, p.exclude_self);
+                        const unsigned long long m = __ballot(fwd);
+                        if (m) {
+                            if (fwd) {
+                                const int at = nbuf + __popcll(m & lt);
+                                s_fq[wave][at] = qq;
+                                s_fid[wave][at] = idj[rb];
+                                // l2: sqrt(exact distance) <= sqrt(s_hi) + |x - x~|max + |q - q~|, the query's share is
+                                // added by the reader; dot: exact product >= q~.x~ - slack
+                                if (METRIC == 1) {
+                                    const float s_hi = fmaf(-2.0f, acc[rb][r], (s2.x + xn[rb]) * (1.0f + c32));
+                                    s_fv[wave][at] = sqrtf(fmaxf(s_hi, 0.f)) * 1.000001f + cxm;
+                                } else {
+                                    s_fv[wave][at] = acc[rb][r] - s2.y * 1.000001f;
+                                }
+                            }
+                            nbuf += __popcll(m);
+                            if (nbuf >= 64) {
+                                flush(64);
+                                const int rest = nbuf - 64;
+                                int32_t tq2 = 0, ti2 = 0;
+                                float tv2 = 0.f;
+                                if (lane < rest) { tq2 = s_fq[wave][64 + lane]; ti2 = s_fid[wave][64 + lane]; tv2 = s_fv[wave][64 + lane]; }
+                                if (lane < rest) { s_fq[wave][lane] = tq2; s_fid[wave][lane] = ti2; s_fv[wave][lane] = tv2; }
+                                nbuf = rest;
                             }
                         }
-                        nbuf += __popcll(m);
-                        if (nbuf >= 64) {
-                            flush(64);
-                            const int rest = nbuf - 64;
-                            int32_t tq2 = 0, ti2 = 0;
-                            float tv2 = 0.f;
-                            if (lane < rest) { tq2 = s_fq[wave][64 + lane]; ti2 = s_fid[wave][64 + lane]; tv2 = s_fv[wave][64 + lane]; }
-                            if (lane < rest) { s_fq[wave][lane] = tq2; s_fid[wave][lane] = ti2; s_fv[wave][lane] = tv2; }
-                            nbuf = rest;
+                    }
+                }
+                if (METRIC == 1 && tight >= p.k) {
+                    // Roughly k or more rows of this tile sit inside 0.985 sqrt(tau).  With
+                    //   v = sqrt(s_hi) + |x - x~|max >= sqrt(exact distance) - |q - q~|
+                    // (s_hi = |q~ - x~|^2 rounded up), the k-th smallest v among the RB*16 rows this 16-lane
+                    // group holds for the query bounds the query's k-th best distance from above.
+                    const int32_t qq = __float_as_int(sc.z), qidq = __float_as_int(sc.w);
+                    const float2 s2 = s_slot2[wave][slot];
+                    float v[RB];
+#pragma unroll
+                    for (int rb = 0; rb < RB; rb++) {
+                        const bool ok = idj[rb] >= 0 && !self_excluded(idj[rb], qidq, p.exclude_self);
+                        const float s_hi = fmaf(-2.0f, acc[rb][r], (s2.x + xn[rb]) * (1.0f + c32));
+                        v[rb] = ok ? sqrtf(fmaxf(s_hi, 0.f)) * 1.000001f + cxm : HUGE_VALF;
+                    }
+                    int rank[RB];
+#pragma unroll
+                    for (int mb = 0; mb < RB; mb++) rank[mb] = 0;
+                    for (int j = 0; j < 16; j++) {
+                        const int src = 16 * g + j;
+#pragma unroll
+                        for (int ob = 0; ob < RB; ob++) {
+                            const float o = __shfl(v[ob], src);
+#pragma unroll
+                            for (int mb = 0; mb < RB; mb++)
+                                rank[mb] += (o < v[mb] || (o == v[mb] && (j < i16 || (j == i16 && ob < mb)))) ? 1 : 0;
+                        }
+                    }
+#pragma unroll
+                    for (int mb = 0; mb < RB; mb++) {
+                        if (rank[mb] == p.k - 1 && v[mb] < HUGE_VALF) {
+                            const float b = (v[mb] + s2.y) * 1.000001f;
+                            atomicMin(&p.tau[qq], enc_f32(b * b * 1.000001f));
                         }
                     }
                 }
             }
-            if (METRIC == 1 && tight >= p.k) {
-                // Roughly k or more rows of this tile sit inside 0.985 sqrt(tau).  With
-                //   v = sqrt(s_hi) + |x - x~|max >= sqrt(exact distance) - |q - q~|
-                // (s_hi = |q~ - x~|^2 rounded up), the k-th smallest v among the 64 rows this 16-lane
-                // group holds for the query bounds the query's k-th best distance from above.
-                const int32_t qq = __float_as_int(sc.z), qidq = __float_as_int(sc.w);
-                const float2 s2 = s_slot2[wave][slot];
-                float v[4];
-#pragma unroll
-                for (int rb = 0; rb < 4; rb++) {
-                    const bool ok = idj[rb] >= 0 && !self_excluded(idj[rb], qidq, p.exclude_self);
-                    const float s_hi = fmaf(-2.0f, acc[rb][r], (s2.x + xnc[rb]) * (1.0f + c32));
-                    v[rb] = ok ? sqrtf(fmaxf(s_hi, 0.f)) * 1.000001f + cxm : HUGE_VALF;
-                }
-                int rank[4] = {0, 0, 0, 0};
-                for (int j = 0; j < 16; j++) {
-                    const int src = 16 * g + j;
-#pragma unroll
-                    for (int ob = 0; ob < 4; ob++) {
-                        const float o = __shfl(v[ob], src);
-#pragma unroll
-                        for (int mb = 0; mb < 4; mb++)
-                            rank[mb] += (o < v[mb] || (o == v[mb] && (j < i16 || (j == i16 && ob < mb)))) ? 1 : 0;
-                    }
-                }
-#pragma unroll
-                for (int mb = 0; mb < 4; mb++) {
-                    if (rank[mb] == p.k - 1 && v[mb] < HUGE_VALF) {
-                        const float b = (v[mb] + s2.y) * 1.000001f;
-                        atomicMin(&p.tau[qq], enc_f32(b * b * 1.000001f));
-                    }
-                }
-            }
         }
-        if (!more) break;
     }
     flush(nbuf);
 }
 
-template <int METRIC>
+template <int METRIC, int RB>
 static void launch_leafscan_f16_m(const LeafScanParams &p, hipStream_t stream)
 {
     const int64_t n = p.unit_end - p.unit_begin;
     if (n <= 0) return;
-    const int64_t resident = (int64_t)p.num_cus * ls16_waves(p.ks);       // workgroups the chip holds at once
+    const int64_t resident = (int64_t)p.num_cus * ls16_waves(p.ks, RB);   // workgroups the chip holds at once
     dim3 grid((unsigned)std::min<int64_t>((n + 3) / 4, resident)), block(256);
-#define DPF_LB(KS) hipLaunchKernelGGL((k_leafscan_f16<KS, METRIC>), grid, block, 0, stream, p, p.Q16, p.base16)
+#define DPF_LB(KS) hipLaunchKernelGGL((k_leafscan_f16<KS, METRIC, RB>), grid, block, 0, stream, p, p.Q16, p.base16)
     switch (p.ks) {
     case 1: DPF_LB(1); break;
     case 2: DPF_LB(2); break;
@@ -1661,8 +1639,8 @@ void launch_leafscan(int metric, int chunks16, const LeafScanParams &p, hipStrea
 {
     if (p.ntiles <= 0) return;
     if (p.engine == 2) {
-        if (metric == 0) launch_leafscan_f16_m<0>(p, stream);
-        else launch_leafscan_f16_m<1>(p, stream);
+        if (metric == 0) launch_leafscan_f16_m<0, 4>(p, stream);
+        else launch_leafscan_f16_m<1, 4>(p, stream);
         return;
     }
     if (p.engine == 1) {

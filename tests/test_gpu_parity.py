@@ -351,3 +351,55 @@ def test_bucket_major_with_row_shards():
             d2 = ((X[c].astype(np.float64) - Q[q].astype(np.float64)) ** 2).sum(axis=1)
             order = np.lexsort((c, d2))[:10]
             assert np.array_equal(ids[q, :len(order)], c[order])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("metric", ["l2", "dot"])
+@pytest.mark.parametrize("kind", ["huge", "tiny", "mixed", "near_duplicates", "zeros"])
+def test_fp16_filter_is_exact_on_hostile_values(metric, kind):
+    # The bucket-major filter works on fp16 copies whose rounding distance is measured per row, so
+    # values outside the fp16 range (clamped), below its normal range (flushed) or differing only
+    # in bits fp16 drops must still give the gather path's answer bit for bit.
+    params, X, Q, pick = make_problem(n=6000, nq=120, dim=100, bucket_overflow=40, table_num=2, permutation_num=2,
+                                      n_clusters=5)
+    rng = np.random.default_rng(7)
+    if kind == "huge":
+        X = X * np.float32(3.0e4); Q = Q * np.float32(3.0e4)            # many elements beyond 65504
+    elif kind == "tiny":
+        X = X * np.float32(1.0e-6); Q = Q * np.float32(1.0e-6)          # everything below 2^-14
+    elif kind == "mixed":
+        s = (10.0 ** rng.integers(-7, 6, size=(1, X.shape[1]))).astype(np.float32)
+        X = X * s; Q = Q * s
+    elif kind == "near_duplicates":
+        base = X[:60]
+        X = (base[rng.integers(0, 60, size=X.shape[0])] * (1 + 1e-4 * rng.standard_normal(X.shape))).astype(np.float32)
+        Q = (X[pick] * (1 + 1e-5 * rng.standard_normal(Q.shape))).astype(np.float32)
+    elif kind == "zeros":
+        X[::7] = 0; Q[::5] = 0
+    X = np.ascontiguousarray(X, dtype=np.float32); Q = np.ascontiguousarray(Q, dtype=np.float32)
+    fast = DpfIndex(params, metric=metric)
+    slow = DpfIndex(dict(params, flags=2), metric=metric)
+    fast.fit(X)
+    slow.fit(X)
+    for k in (1, 10, 64):
+        fi, fs = fast.query_topk(pick, Q, steps=2, k=k)
+        si, ss = slow.query_topk(pick, Q, steps=2, k=k)
+        assert np.array_equal(fi, si)
+        assert np.array_equal(fs, ss, equal_nan=True)
+
+
+@pytest.mark.gpu
+def test_bucket_major_many_queries_per_bucket_and_repeated_batches():
+    # a few buckets probed by hundreds of queries (several work units per tile), batches of
+    # changing size through one handle (workspaces are reused and regrown)
+    params, X, Q, pick = make_problem(n=5000, nq=1500, dim=64, bucket_overflow=100, table_num=2, permutation_num=1,
+                                      n_clusters=3)
+    fast = DpfIndex(params, metric="l2")
+    slow = DpfIndex(dict(params, flags=2), metric="l2")
+    fast.fit(X)
+    slow.fit(X)
+    for nq in (1500, 7, 300, 1500):
+        fi, fs = fast.query_topk(pick[:nq], Q[:nq], steps=1, k=10)
+        assert fast.stats()["last_path"] == 1
+        si, ss = slow.query_topk(pick[:nq], Q[:nq], steps=1, k=10)
+        assert np.array_equal(fi, si) and np.array_equal(fs, ss, equal_nan=True)
