@@ -88,10 +88,12 @@ typedef struct dpf_stats {
     int64_t last_raw_candidates; /* last batch: ids visited before set union       */
     int64_t last_unique_candidates; /* last batch: sum of per-query set sizes      */
     double  last_ms_hash, last_ms_probe, last_ms_dedupe, last_ms_rerank;
-    double  last_ms_scan;        /* bucket-major scan kernel of the last top-k batch (0: gather path) */
+    double  last_ms_scan;        /* bucket-major scan kernel of the last top-k batch, summed over its
+                                    launches (0: gather path) */
     int64_t last_path;           /* rerank path of the last top-k batch: 0 gather, 1 bucket-major */
     int64_t last_pairs;          /* (query, bucket) incidences of the last bucket-major batch */
     int64_t last_forwarded;      /* candidates forwarded to the exact rerank by the scan */
+    int64_t last_scan_launches;  /* launches of the scan kernel in the last bucket-major batch */
     int64_t snapshot_bytes;      /* HBM bytes of the forest snapshot               */
     int64_t base_bytes;          /* HBM bytes of the resident base rows            */
 } dpf_stats;
@@ -171,7 +173,9 @@ int dpf_get_stats(dpf_index *ix, dpf_stats *out);
  * its own definition: the gather rerank (dpf_stats.last_path 0) reads every
  * candidate row + id, the query rows, and writes the results; the bucket-major
  * scan (last_path 1) reads every touched bucket's rows + ids once, one query row +
- * threshold per (query, bucket) incidence, and writes the forwarded pairs. */
+ * threshold per (query, bucket) incidence, and writes the forwarded pairs.  On the
+ * bucket-major path *ms and *algorithmic_bytes are sums over the scan kernel's
+ * launches of the batch (dpf_stats.last_scan_launches of them). */
 int dpf_last_rerank_profile(dpf_index *ix, double *ms, int64_t *algorithmic_bytes);
 /* enable (1) / disable (0) the per-stage HIP-event timing (adds stream syncs) */
 int dpf_set_profiling(dpf_index *ix, int32_t on);

@@ -33,7 +33,8 @@ class DpfStats(C.Structure):
         "last_raw_candidates", "last_unique_candidates")] + [
         (n, C.c_double) for n in ("last_ms_hash", "last_ms_probe", "last_ms_dedupe", "last_ms_rerank",
                                   "last_ms_scan")] + [
-        (n, C.c_int64) for n in ("last_path", "last_pairs", "last_forwarded", "snapshot_bytes", "base_bytes")]
+        (n, C.c_int64) for n in ("last_path", "last_pairs", "last_forwarded", "last_scan_launches", "snapshot_bytes",
+                                 "base_bytes")]
 
 
 EXPORTS = (

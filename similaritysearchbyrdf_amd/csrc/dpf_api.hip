@@ -60,7 +60,7 @@ struct dpf_index {
     int64_t base_rows = 0;                   // resident rows: ids row_begin .. row_begin+base_rows-1
 
     DevBuf d_roots, d_dnodes, d_leaf_off, d_ids;
-    DevBuf ws_emit_v;
+    DevBuf ws_emit_v, ws_leaf_units, ws_unit_off;
     DevBuf d_leaf_tile0, ws_units;           // first tile of each bucket; work units of the batch
     int num_cus = 256;
     DevBuf d_tiles;                          // {bucket, first id slot, rows, 0} per tile
@@ -82,7 +82,8 @@ struct dpf_index {
     DevBuf ws_stage;                                  // fit staging
     DevBuf ws_lq_cnt, ws_lq_off, ws_lq_cursor, ws_leaf_queries, ws_seed_cand, ws_seed_cnt, ws_seed_ids,
         ws_seed_scores, ws_emit, ws_emit_cnt, ws_flag, ws_qnorm, ws_tau, ws_slack;
-    hipEvent_t ev_scan[2]{};
+    hipEvent_t ev_scan[4]{};                          // first and second pass of the scan
+    int scan_launches = 0;
     unsigned long long *d_short_hash = nullptr;
     int64_t *pinned = nullptr;                        // host-pinned scratch (8 x int64)
     hipEvent_t ev[6]{};
@@ -170,7 +171,7 @@ extern "C" int dpf_create(const dpf_config *cfg, dpf_index **out)
     if (e == hipSuccess) e = hipMemset(ix->d_short_hash, 0, sizeof(unsigned long long));
     if (e == hipSuccess) e = hipHostMalloc((void **)&ix->pinned, 8 * sizeof(int64_t), hipHostMallocDefault);
     for (int i = 0; i < 6 && e == hipSuccess; i++) e = hipEventCreate(&ix->ev[i]);
-    for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipEventCreate(&ix->ev_scan[i]);
+    for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipEventCreate(&ix->ev_scan[i]);
     if (e != hipSuccess) {
         std::string m = std::string("dpf_create: ") + hipGetErrorString(e);
         delete ix;
@@ -207,8 +208,8 @@ extern "C" void dpf_destroy(dpf_index *ix)
     if (ix->d_short_hash) (void)hipFree(ix->d_short_hash);
     if (ix->pinned) (void)hipHostFree(ix->pinned);
     for (int i = 0; i < 6; i++) if (ix->ev[i]) (void)hipEventDestroy(ix->ev[i]);
-    for (int i = 0; i < 2; i++) if (ix->ev_scan[i]) (void)hipEventDestroy(ix->ev_scan[i]);
-    DevBuf *more[] = {&ix->ws_emit_v, &ix->d_leaf_tile0, &ix->ws_units, &ix->d_tiles, &ix->d_tile_leaf, &ix->d_tile_row0, &ix->ws_lq_cnt, &ix->ws_lq_off, &ix->ws_lq_cursor, &ix->ws_leaf_queries,
+    for (int i = 0; i < 4; i++) if (ix->ev_scan[i]) (void)hipEventDestroy(ix->ev_scan[i]);
+    DevBuf *more[] = {&ix->ws_emit_v, &ix->ws_leaf_units, &ix->ws_unit_off, &ix->d_leaf_tile0, &ix->ws_units, &ix->d_tiles, &ix->d_tile_leaf, &ix->d_tile_row0, &ix->ws_lq_cnt, &ix->ws_lq_off, &ix->ws_lq_cursor, &ix->ws_leaf_queries,
                       &ix->ws_seed_cand, &ix->ws_seed_cnt, &ix->ws_seed_ids, &ix->ws_seed_scores, &ix->ws_emit, &ix->ws_emit_cnt,
                       &ix->d_base16, &ix->ws_q16, &ix->d_base16n, &ix->ws_q16n, &ix->d_base16e, &ix->ws_q16e, &ix->ws_flag, &ix->ws_qnorm, &ix->ws_tau, &ix->ws_slack};
     for (DevBuf *b : more) b->release();
@@ -592,7 +593,7 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     HIPCHECK(ix, ix->ws_seed_scores.ensure((size_t)nq * k * 8));
     HIPCHECK(ix, ix->ws_emit.ensure((size_t)nq * EMIT_CAP * 4));
     HIPCHECK(ix, ix->ws_emit_cnt.ensure((size_t)nq * 4));
-    HIPCHECK(ix, ix->ws_flag.ensure(32));             // overflow flag, unit count, unit cursor
+    HIPCHECK(ix, ix->ws_flag.ensure(16));
     HIPCHECK(ix, ix->ws_qnorm.ensure((size_t)nq * 4));
     HIPCHECK(ix, ix->ws_tau.ensure((size_t)nq * 4));
     HIPCHECK(ix, ix->ws_slack.ensure((size_t)nq * 4));
@@ -603,17 +604,22 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     HIPCHECK(ix, hipMemsetAsync(ix->ws_lq_cnt.p, 0, (size_t)(nl + 1) * 4, stream));
     HIPCHECK(ix, hipMemsetAsync(ix->ws_lq_cursor.p, 0, (size_t)(nl + 1) * 4, stream));
     HIPCHECK(ix, hipMemsetAsync(ix->ws_emit_cnt.p, 0, (size_t)nq * 4, stream));
-    HIPCHECK(ix, hipMemsetAsync(ix->ws_flag.p, 0, 32, stream));
+    HIPCHECK(ix, hipMemsetAsync(ix->ws_flag.p, 0, 16, stream));
     ProbeParams pp;
     fill_probe_params(ix, pp, d_qids, steps);
     pp.lq_cnt = ix->ws_lq_cnt.as<uint32_t>();
     launch_probe(0, pp, nq, stream);
     launch_scan_i32(ix->ws_lq_cnt.as<int32_t>(), nl, ix->ws_lq_off.as<int64_t>(), stream);
     const int engine = [&] { const char *e = getenv("DPF_LEAFSCAN"); return (e && !strcmp(e, "valu")) ? 0 : ((e && !strcmp(e, "f32")) || ix->ks16 < 0 ? 1 : 2); }();
-    unsigned long long *d_unit_count = (unsigned long long *)ix->ws_flag.p + 1, *d_unit_cursor = d_unit_count + 1;
-    if (engine == 2) launch_unit_count(ix->ws_lq_cnt.as<uint32_t>(), ix->d_leaf_tile0.as<uint32_t>(), nl, d_unit_count, stream);
+    ix->pinned[2] = 0;
+    if (engine == 2) {
+        HIPCHECK(ix, ix->ws_leaf_units.ensure((size_t)(nl + 1) * 4));
+        HIPCHECK(ix, ix->ws_unit_off.ensure((size_t)(nl + 2) * 8));
+        launch_unit_count(ix->ws_lq_cnt.as<uint32_t>(), ix->d_leaf_tile0.as<uint32_t>(), nl, ix->ws_leaf_units.as<int32_t>(),
+                          ix->ws_unit_off.as<int64_t>(), stream);
+        HIPCHECK(ix, hipMemcpyAsync(ix->pinned + 2, ix->ws_unit_off.as<int64_t>() + nl, 8, hipMemcpyDeviceToHost, stream));
+    }
     HIPCHECK(ix, hipMemcpyAsync(ix->pinned, ix->ws_lq_off.as<int64_t>() + nl, 8, hipMemcpyDeviceToHost, stream));
-    HIPCHECK(ix, hipMemcpyAsync(ix->pinned + 2, d_unit_count, 8, hipMemcpyDeviceToHost, stream));
     HIPCHECK(ix, hipStreamSynchronize(stream));
     const int64_t pairs = ix->pinned[0], nunits = ix->pinned[2];
     // unit descriptors index leaf_queries[] and the unit list with 32 bits
@@ -678,13 +684,14 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
         lp.Q16 = ix->ws_q16.as<uint16_t>();
         HIPCHECK(ix, ix->ws_units.ensure((size_t)std::max<int64_t>(nunits, 1) * 16));
         launch_units(ix->ws_lq_cnt.as<uint32_t>(), ix->ws_lq_off.as<int64_t>(), ix->d_leaf_tile0.as<uint32_t>(),
-                     (const uint4 *)ix->d_tiles.p, nl, d_unit_cursor, (uint4 *)ix->ws_units.p, stream);
+                     (const uint4 *)ix->d_tiles.p, nl, ix->ws_unit_off.as<int64_t>(), (uint4 *)ix->ws_units.p, stream);
         lp.units = (const uint4 *)ix->ws_units.p; lp.unit_begin = 0; lp.unit_end = nunits; lp.num_cus = ix->num_cus;
         HIPCHECK(ix, ix->ws_emit_v.ensure((size_t)nq * EMIT_CAP * 4));
         lp.emit_v = ix->ws_emit_v.as<float>();
     }
     lp.debug = getenv("DPF_LS_DEBUG") ? atoi(getenv("DPF_LS_DEBUG")) : 0;
     lp.emit = ix->ws_emit.as<int32_t>(); lp.emit_cnt = ix->ws_emit_cnt.as<int32_t>(); lp.emit_cap = EMIT_CAP;
+    ix->scan_launches = 1;
     HIPCHECK(ix, hipEventRecord(ix->ev_scan[0], stream));
     if (engine == 2) {
         // a first slice of the units, then thresholds refined from what it forwarded, then the rest
@@ -692,12 +699,18 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
         const int64_t n_first = std::min<int64_t>(nunits, nunits * first_permille / 1000);
         lp.unit_end = n_first;
         launch_leafscan(ix->cfg.metric, (int)(ix->dpad / 4), lp, stream);
-        if (n_first > 0)
+        HIPCHECK(ix, hipEventRecord(ix->ev_scan[1], stream));
+        if (n_first > 0) {
             launch_refine(ix->cfg.metric, lp.emit, lp.emit_v, lp.emit_cnt, EMIT_CAP, k, nq, lp.q16_err, lp.tau, stream);
+            ix->scan_launches = 2;
+        }
         lp.unit_begin = n_first; lp.unit_end = nunits;
+    } else {
+        HIPCHECK(ix, hipEventRecord(ix->ev_scan[1], stream));
     }
+    HIPCHECK(ix, hipEventRecord(ix->ev_scan[2], stream));
     launch_leafscan(ix->cfg.metric, (int)(ix->dpad / 4), lp, stream);
-    HIPCHECK(ix, hipEventRecord(ix->ev_scan[1], stream));
+    HIPCHECK(ix, hipEventRecord(ix->ev_scan[3], stream));
     launch_overflow_flag(ix->ws_emit_cnt.as<int32_t>(), nq, EMIT_CAP, ix->ws_flag.as<int32_t>(), stream);
     HIPCHECK(ix, hipMemcpyAsync(ix->pinned + 1, ix->ws_flag.p, 4, hipMemcpyDeviceToHost, stream));
     HIPCHECK(ix, hipStreamSynchronize(stream));
@@ -930,11 +943,14 @@ extern "C" int dpf_get_stats(dpf_index *ix, dpf_stats *out)
     ix->st.last_path = ix->last_valid ? ix->last_path : 0;
     ix->st.last_forwarded = 0;
     ix->st.last_ms_scan = 0;
+    ix->st.last_scan_launches = 0;
     if (ix->last_valid && ix->last_path == 1) {
         ix->st.last_forwarded = ix->st.last_unique_candidates;
         ix->st.last_unique_candidates = 0;          // the sets are not materialised on this path
-        float t = 0;
-        if (hipEventElapsedTime(&t, ix->ev_scan[0], ix->ev_scan[1]) == hipSuccess) ix->st.last_ms_scan = t;
+        float t = 0, t2 = 0;
+        if (hipEventElapsedTime(&t, ix->ev_scan[0], ix->ev_scan[1]) == hipSuccess &&
+            hipEventElapsedTime(&t2, ix->ev_scan[2], ix->ev_scan[3]) == hipSuccess) ix->st.last_ms_scan = t + t2;
+        ix->st.last_scan_launches = ix->scan_launches;
     }
     if (ix->profiling && ix->last_valid) {
         float ms = 0;
@@ -956,8 +972,14 @@ extern "C" int dpf_last_rerank_profile(dpf_index *ix, double *ms, int64_t *algor
     HIPCHECK(ix, hipSetDevice(ix->cfg.device));
     HIPCHECK(ix, hipEventSynchronize(ix->ev[5]));
     float t = 0;
-    if (ix->last_path == 1) HIPCHECK(ix, hipEventElapsedTime(&t, ix->ev_scan[0], ix->ev_scan[1]));
-    else HIPCHECK(ix, hipEventElapsedTime(&t, ix->ev[4], ix->ev[5]));
+    if (ix->last_path == 1) {
+        float t2 = 0;
+        HIPCHECK(ix, hipEventElapsedTime(&t, ix->ev_scan[0], ix->ev_scan[1]));
+        HIPCHECK(ix, hipEventElapsedTime(&t2, ix->ev_scan[2], ix->ev_scan[3]));
+        t += t2;
+    } else {
+        HIPCHECK(ix, hipEventElapsedTime(&t, ix->ev[4], ix->ev[5]));
+    }
     int64_t raw = 0, uniq = 0;
     int rc = last_totals(ix, &raw, &uniq);
     if (rc != DPF_OK) return rc;

@@ -1129,34 +1129,25 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 static constexpr uint32_t UNIT_QUERIES = 128;
 __device__ inline uint32_t units_of_leaf(uint32_t cnt, uint32_t ntl) { return cnt ? ntl * ((cnt + UNIT_QUERIES - 1u) / UNIT_QUERIES) : 0u; }
 
+// per-bucket unit counts; their exclusive scan places each bucket's units (bucket order, so the
+// unit list is the same for the same batch on every run)
 __global__ __launch_bounds__(256) void k_unit_count(const uint32_t *__restrict__ lq_cnt, const uint32_t *__restrict__ leaf_tile0,
-                                                    int64_t nl, unsigned long long *__restrict__ total)
+                                                    int64_t nl, int32_t *__restrict__ leaf_units)
 {
     const int64_t l = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    unsigned long long n = 0;
-    if (l < nl) n = units_of_leaf(lq_cnt[l], leaf_tile0[l + 1] - leaf_tile0[l]);
-    for (int o = 32; o; o >>= 1) n += __shfl_down(n, o);
-    if ((threadIdx.x & 63) == 0 && n) atomicAdd(total, n);
+    if (l < nl) leaf_units[l] = (int32_t)units_of_leaf(lq_cnt[l], leaf_tile0[l + 1] - leaf_tile0[l]);
 }
 
 __global__ __launch_bounds__(256) void k_units(const uint32_t *__restrict__ lq_cnt, const int64_t *__restrict__ lq_off,
                                                const uint32_t *__restrict__ leaf_tile0, const uint4 *__restrict__ tiles,
-                                               int64_t nl, unsigned long long *__restrict__ cursor, uint4 *__restrict__ units)
+                                               int64_t nl, const int64_t *__restrict__ unit_off, uint4 *__restrict__ units)
 {
     const int64_t l = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    uint32_t cnt = 0, t0 = 0, ntl = 0;
-    if (l < nl) { cnt = lq_cnt[l]; t0 = leaf_tile0[l]; ntl = leaf_tile0[l + 1] - t0; }
-    const uint32_t n = units_of_leaf(cnt, ntl);
-    // one reservation per wave, a prefix sum inside it
-    uint32_t inc = n;
-    for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(inc, o); if (lane >= o) inc += v; }
-    const uint32_t wave_total = __shfl(inc, 63);
-    if (wave_total == 0) return;
-    unsigned long long base = 0;
-    if (lane == 63) base = atomicAdd(cursor, (unsigned long long)wave_total);
-    base = __shfl(base, 63) + (inc - n);
-    if (n == 0) return;
+    if (l >= nl) return;
+    const uint32_t cnt = lq_cnt[l];
+    if (cnt == 0) return;
+    const uint32_t t0 = leaf_tile0[l], ntl = leaf_tile0[l + 1] - t0;
+    int64_t base = unit_off[l];
     const uint32_t lqb = (uint32_t)lq_off[l];
     for (uint32_t t = 0; t < ntl; t++) {
         const uint4 td = tiles[t0 + t];
@@ -1191,14 +1182,17 @@ __global__ __launch_bounds__(256) void k_tile_maxnorm(uint4 *__restrict__ tiles,
     tiles[t] = td;
 }
 
-void launch_unit_count(const uint32_t *lq_cnt, const uint32_t *leaf_tile0, int64_t nl, unsigned long long *total, hipStream_t stream)
+// unit_off[0..nl] = exclusive scan of the per-bucket unit counts (leaf_units is scratch, nl ints)
+void launch_unit_count(const uint32_t *lq_cnt, const uint32_t *leaf_tile0, int64_t nl, int32_t *leaf_units, int64_t *unit_off,
+                       hipStream_t stream)
 {
-    if (nl > 0) hipLaunchKernelGGL(k_unit_count, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, stream, lq_cnt, leaf_tile0, nl, total);
+    if (nl > 0) hipLaunchKernelGGL(k_unit_count, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, stream, lq_cnt, leaf_tile0, nl, leaf_units);
+    launch_scan_i32(leaf_units, nl, unit_off, stream);
 }
 void launch_units(const uint32_t *lq_cnt, const int64_t *lq_off, const uint32_t *leaf_tile0, const uint4 *tiles, int64_t nl,
-                  unsigned long long *cursor, uint4 *units, hipStream_t stream)
+                  const int64_t *unit_off, uint4 *units, hipStream_t stream)
 {
-    if (nl > 0) hipLaunchKernelGGL(k_units, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, stream, lq_cnt, lq_off, leaf_tile0, tiles, nl, cursor, units);
+    if (nl > 0) hipLaunchKernelGGL(k_units, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, stream, lq_cnt, lq_off, leaf_tile0, tiles, nl, unit_off, units);
 }
 void launch_tile_maxnorm(uint4 *tiles, int64_t ntiles, const int32_t *ids, const float *norms, const float *errs, int64_t row_begin,
                          int64_t row_end, hipStream_t stream)
