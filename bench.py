@@ -58,7 +58,7 @@ def workload(name, n, nq):
     return params, X, Q, pick, steps
 
 
-def pmc_traffic(workload_name, n, nq, world, kernel):
+def pmc_traffic(workload_name, n, nq, world, kernel, steps):
     """HBM-side bytes per rerank launch from the committed rocprofv3 PMC passes
     (FETCH_SIZE doubled as gfx950 needs, plus WRITE_SIZE); None when no pass
     matches this configuration."""
@@ -69,7 +69,8 @@ def pmc_traffic(workload_name, n, nq, world, kernel):
     if not files:
         return None
     with open(files[-1]) as f:
-        return json.load(f).get("traffic_bytes_per_launch")
+        rec = json.load(f)
+    return rec.get("traffic_bytes_per_launch") if rec.get("search_steps", 1) == steps else None
 
 
 def ground_truth_l2(torch, dX, dQ, k, chunk=500):
@@ -274,7 +275,7 @@ def main():
                        "misflag_events": st["misflag_events"], "short_hash_events": st["short_hash_events"]},
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(args.workload, n, nq, world, kernel),
+                         "traffic": pmc_traffic(args.workload, n, nq, world, kernel, steps),
                          "algorithmic_bytes_per_launch": rr_bytes, "ms_per_launch": rr,
                          "launches_per_batch": launches},
         }
