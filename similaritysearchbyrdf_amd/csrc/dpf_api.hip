@@ -60,7 +60,7 @@ struct dpf_index {
     int64_t base_rows = 0;                   // resident rows: ids row_begin .. row_begin+base_rows-1
 
     DevBuf d_roots, d_dnodes, d_leaf_off, d_ids;
-    DevBuf ws_emit_v, ws_leaf_units, ws_unit_off;
+    DevBuf ws_emit_v, ws_leaf_units, ws_unit_off, ws_q_leaves, ws_q_leaf_cnt;
     DevBuf d_leaf_tile0, ws_units;           // first tile of each bucket; work units of the batch
     int num_cus = 256;
     DevBuf d_tiles;                          // {bucket, first id slot, rows, 0} per tile
@@ -209,7 +209,7 @@ extern "C" void dpf_destroy(dpf_index *ix)
     if (ix->pinned) (void)hipHostFree(ix->pinned);
     for (int i = 0; i < 6; i++) if (ix->ev[i]) (void)hipEventDestroy(ix->ev[i]);
     for (int i = 0; i < 4; i++) if (ix->ev_scan[i]) (void)hipEventDestroy(ix->ev_scan[i]);
-    DevBuf *more[] = {&ix->ws_emit_v, &ix->ws_leaf_units, &ix->ws_unit_off, &ix->d_leaf_tile0, &ix->ws_units, &ix->d_tiles, &ix->d_tile_leaf, &ix->d_tile_row0, &ix->ws_lq_cnt, &ix->ws_lq_off, &ix->ws_lq_cursor, &ix->ws_leaf_queries,
+    DevBuf *more[] = {&ix->ws_emit_v, &ix->ws_leaf_units, &ix->ws_unit_off, &ix->ws_q_leaves, &ix->ws_q_leaf_cnt, &ix->d_leaf_tile0, &ix->ws_units, &ix->d_tiles, &ix->d_tile_leaf, &ix->d_tile_row0, &ix->ws_lq_cnt, &ix->ws_lq_off, &ix->ws_lq_cursor, &ix->ws_leaf_queries,
                       &ix->ws_seed_cand, &ix->ws_seed_cnt, &ix->ws_seed_ids, &ix->ws_seed_scores, &ix->ws_emit, &ix->ws_emit_cnt,
                       &ix->d_base16, &ix->ws_q16, &ix->d_base16n, &ix->ws_q16n, &ix->d_base16e, &ix->ws_q16e, &ix->ws_flag, &ix->ws_qnorm, &ix->ws_tau, &ix->ws_slack};
     for (DevBuf *b : more) b->release();
@@ -508,6 +508,7 @@ static void fill_probe_params(dpf_index *ix, ProbeParams &pp, const int32_t *d_q
     pp.cand = ix->ws_arena.as<int32_t>();
     pp.cnt = ix->ws_cnt.as<int32_t>();
     pp.lq_cnt = nullptr; pp.lq_off = nullptr; pp.lq_cursor = nullptr; pp.leaf_queries = nullptr;
+    pp.q_leaves = nullptr; pp.q_leaf_cnt = nullptr; pp.q_leaf_cap = 0; pp.q_leaf_overflow = nullptr;
     pp.seed_cand = nullptr; pp.seed_cnt = nullptr; pp.seed_cap = 0;
 }
 
@@ -608,6 +609,20 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     ProbeParams pp;
     fill_probe_params(ix, pp, d_qids, steps);
     pp.lq_cnt = ix->ws_lq_cnt.as<uint32_t>();
+    // the buckets each query reaches are remembered (up to a cap) so that the lists can be filled
+    // without walking the forest again
+    {
+        int nsub = 0;
+        for (int s2 = 0; s2 < ix->geo.num_parts; s2++) nsub += __builtin_popcount((unsigned)s2) <= steps;
+        const int64_t most = (int64_t)L * 28 * nsub;          // every probe in a bucket of its own
+        pp.q_leaf_cap = (int32_t)std::min<int64_t>(most, 4096);
+        if (const char *e = getenv("DPF_Q_LEAF_CAP")) pp.q_leaf_cap = std::max(1, atoi(e));   // tests: force truncation
+        HIPCHECK(ix, ix->ws_q_leaves.ensure((size_t)nq * pp.q_leaf_cap * 4));
+        HIPCHECK(ix, ix->ws_q_leaf_cnt.ensure((size_t)nq * 4));
+        pp.q_leaves = ix->ws_q_leaves.as<uint32_t>();
+        pp.q_leaf_cnt = ix->ws_q_leaf_cnt.as<int32_t>();
+        pp.q_leaf_overflow = ix->ws_flag.as<int32_t>() + 1;
+    }
     launch_probe(0, pp, nq, stream);
     launch_scan_i32(ix->ws_lq_cnt.as<int32_t>(), nl, ix->ws_lq_off.as<int64_t>(), stream);
     const int engine = [&] { const char *e = getenv("DPF_LEAFSCAN"); return (e && !strcmp(e, "valu")) ? 0 : ((e && !strcmp(e, "f32")) || ix->ks16 < 0 ? 1 : 2); }();
@@ -620,8 +635,10 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
         HIPCHECK(ix, hipMemcpyAsync(ix->pinned + 2, ix->ws_unit_off.as<int64_t>() + nl, 8, hipMemcpyDeviceToHost, stream));
     }
     HIPCHECK(ix, hipMemcpyAsync(ix->pinned, ix->ws_lq_off.as<int64_t>() + nl, 8, hipMemcpyDeviceToHost, stream));
+    HIPCHECK(ix, hipMemcpyAsync(ix->pinned + 3, pp.q_leaf_overflow, 4, hipMemcpyDeviceToHost, stream));
     HIPCHECK(ix, hipStreamSynchronize(stream));
     const int64_t pairs = ix->pinned[0], nunits = ix->pinned[2];
+    const bool lists_truncated = (int32_t)(ix->pinned[3] & 0xffffffff) != 0;
     // unit descriptors index leaf_queries[] and the unit list with 32 bits
     if (pairs >= (int64_t)0xffffffffll || nunits >= (int64_t)0xffffffffll) return DPF_OK;
     if (getenv("DPF_DEBUG")) {
@@ -645,7 +662,8 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     pp.seed_cand = ix->ws_seed_cand.as<int32_t>();
     pp.seed_cnt = ix->ws_seed_cnt.as<int32_t>();
     pp.seed_cap = SEED_CAP;
-    launch_probe(2, pp, nq, stream);
+    if (lists_truncated) launch_probe(2, pp, nq, stream);
+    else launch_fill_lists(pp, nq, stream);
     if (ix->profiling) HIPCHECK(ix, hipEventRecord(ix->ev[2], stream));
 
     // thresholds: exact top-k of each query's seed sample

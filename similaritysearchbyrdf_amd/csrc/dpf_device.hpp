@@ -45,6 +45,10 @@ struct ProbeParams {
     int64_t *bound;           // [nq] min(raw, rows in shard)
     unsigned long long *short_hash_events;
     uint32_t *lq_cnt;         // [num_leaves] optional: (query, bucket) incidence histogram
+    uint32_t *q_leaves;       // [nq][q_leaf_cap] optional: the distinct non-empty buckets each query reached
+    int32_t *q_leaf_cnt;      // [nq] their number (may exceed q_leaf_cap: list truncated)
+    int32_t q_leaf_cap;
+    int32_t *q_leaf_overflow; // set to 1 when any list was truncated
     // mode 1 inputs / outputs
     const int64_t *cand_off;  // [nq + 1] exclusive scan of bound
     int32_t *cand;            // candidate arena
@@ -117,6 +121,7 @@ void launch_hash(int dtype, const void *X, int64_t x_stride, int64_t n, const Ha
                  int32_t *hashes, int32_t *parts, hipStream_t stream);
 size_t hash_shmem_bytes(const HashParams &p);
 void launch_probe(int mode, const ProbeParams &p, int64_t nq, hipStream_t stream);
+void launch_fill_lists(const ProbeParams &p, int64_t nq, hipStream_t stream);
 void launch_leafscan(int metric, int chunks16, const LeafScanParams &p, hipStream_t stream);
 int leafscan_padded_chunks(int nc);
 void launch_unit_count(const uint32_t *lq_cnt, const uint32_t *leaf_tile0, int64_t nl, int32_t *leaf_units, int64_t *unit_off,

@@ -30,7 +30,7 @@
 #pragma clang fp contract(off)
 
 #ifndef LS16_WAVES4
-#define LS16_WAVES4 2
+#define LS16_WAVES4 3
 #endif
 #ifndef LEAFSCAN_WAVES
 #define LEAFSCAN_WAVES 4
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(1024) void k_probe(ProbeParams p)
     __shared__ unsigned long long s_raw;
     __shared__ uint32_t s_wave_tot[16];
     __shared__ uint32_t s_emitted;
-    __shared__ uint32_t s_seed;
+    __shared__ uint32_t s_seed, s_nleaf;
 
     const int64_t q = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(1024) void k_probe(ProbeParams p)
     const int32_t qid = p.qids ? p.qids[q] : -1;
     const int P = 1 << p.pb;
 
-    if (tid == 0) { s_raw = 0; s_emitted = 0; s_seed = 0; }
+    if (tid == 0) { s_raw = 0; s_emitted = 0; s_seed = 0; s_nleaf = 0; }
 
     const int64_t range = p.row_end - p.row_begin;
     const int64_t chunk_bits = (int64_t)p.chunk_words * 32;
@@ -339,22 +339,31 @@ __global__ __launch_bounds__(1024) void k_probe(ProbeParams p)
                 }
                 if ((pair1 >= 0) || (s == P && pair0 >= 0)) {
                     const int sub = half ? pair1 : pair0;
+                    // lane 31 of each half walks the unflipped hash: it is not a probe (RDT:753-758),
+                    // it only names the query's own bucket for the collapse below
                     uint32_t leaf = NO_LEAF;
-                    if (sub >= 0 && i < nprobe)
-                        leaf = walk(p.dnodes, roots[(size_t)sub * p.seg], h ^ (1u << i), p.max_level, p.nbits, p.dns);
-                    // collapse probes that reached the same bucket (same sub-index only:
-                    // buckets of different sub-indexes are disjoint)
-                    bool dup = false;
-                    for (int j = 0; j < nprobe - 1; j++) {
-                        const uint32_t o = __shfl(leaf, (lane & 32) + j);
-                        dup |= (j < i) && (o == leaf);
-                    }
-                    if (dup) leaf = NO_LEAF;
+                    if (sub >= 0 && (i < nprobe || i == 31))
+                        leaf = walk(p.dnodes, roots[(size_t)sub * p.seg], i == 31 ? h : h ^ (1u << i), p.max_level, p.nbits, p.dns);
+                    // Collapse probes that reached the same bucket (same sub-index only: buckets of
+                    // different sub-indexes are disjoint).  A flipped bit either changes the path at its
+                    // level - then the probe ends in a subtree no other probe enters - or it lies below
+                    // the level where the path ends (or in bits the trie does not use) and the probe ends
+                    // in the query's own bucket.  So only the own bucket can be reached more than once.
+                    const uint32_t own = __shfl(leaf, (lane & 32) + 31);
+                    if (i == 31) leaf = NO_LEAF;
+                    const unsigned long long same = __ballot(leaf != NO_LEAF && leaf == own) >> (lane & 32);
+                    if (leaf == own && (same & ((1ull << i) - 1ull) & 0xffffffffull)) leaf = NO_LEAF;
                     uint32_t beg = 0, end = 0;
                     if (leaf != NO_LEAF) { beg = p.leaf_off[leaf]; end = p.leaf_off[leaf + 1]; }
                     if (MODE == 0) {
                         raw_local += end - beg;
-                        if (p.lq_cnt && end > beg) atomicAdd(&p.lq_cnt[leaf], 1u);
+                        if (p.lq_cnt && end > beg) {
+                            atomicAdd(&p.lq_cnt[leaf], 1u);
+                            if (p.q_leaves) {
+                                const uint32_t pos = atomicAdd(&s_nleaf, 1u);
+                                if (pos < (uint32_t)p.q_leaf_cap) p.q_leaves[q * p.q_leaf_cap + pos] = leaf;
+                            }
+                        }
                     } else if (MODE == 2) {
                         if (end > beg) {
                             const uint32_t pos = atomicAdd(&p.lq_cursor[leaf], 1u);
@@ -451,6 +460,10 @@ __global__ __launch_bounds__(1024) void k_probe(ProbeParams p)
             const unsigned long long r = s_raw;
             p.raw[q] = r;
             p.bound[q] = (int64_t)(r < (unsigned long long)range ? r : (unsigned long long)range);
+            if (p.q_leaves) {
+                p.q_leaf_cnt[q] = (int32_t)s_nleaf;
+                if (s_nleaf > (uint32_t)p.q_leaf_cap) *p.q_leaf_overflow = 1;
+            }
         }
     } else if (MODE == 1) {
         if (tid == 0) p.cnt[q] = (int32_t)s_emitted;
@@ -458,6 +471,50 @@ __global__ __launch_bounds__(1024) void k_probe(ProbeParams p)
         __syncthreads();
         if (tid == 0) p.seed_cnt[q] = s_seed < (uint32_t)p.seed_cap ? (int32_t)s_seed : p.seed_cap;
     }
+}
+
+// k_fill_lists: what k_probe<2> does, from the bucket lists k_probe<0> recorded instead of a
+// second walk of the forest: append the query to every bucket it reached, copy the ids of the
+// first buckets into its seed sample.  Only launched when no query's list was truncated.
+__global__ __launch_bounds__(256) void k_fill_lists(ProbeParams p)
+{
+    __shared__ uint32_t s_seed;
+    const int64_t q = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = min(p.q_leaf_cnt[q], p.q_leaf_cap);
+    const int32_t qid = p.qids ? p.qids[q] : -1;
+    if (tid == 0) s_seed = 0;
+    __syncthreads();
+    const uint32_t *mine = p.q_leaves + q * p.q_leaf_cap;
+    for (int j = tid; j < n; j += 256) {
+        const uint32_t leaf = mine[j];
+        const uint32_t pos = atomicAdd(&p.lq_cursor[leaf], 1u);
+        p.leaf_queries[p.lq_off[leaf] + pos] = (int32_t)q;
+    }
+    for (int j = wave; j < n && s_seed < (uint32_t)p.seed_cap; j += 4) {
+        const uint32_t leaf = mine[j];
+        const uint32_t b = p.leaf_off[leaf], e = p.leaf_off[leaf + 1];
+        for (uint32_t k0 = b; k0 < e; k0 += 64) {
+            const uint32_t k = k0 + lane;
+            const int32_t id = k < e ? p.ids[k] : -1;
+            const bool ok = k < e && id >= p.row_begin && id < p.row_end && !self_excluded(id, qid, p.exclude_self);
+            const unsigned long long m = __ballot(ok);
+            if (m == 0) continue;
+            uint32_t at0 = 0;
+            if (lane == 0) at0 = atomicAdd(&s_seed, (uint32_t)__popcll(m));
+            at0 = __shfl(at0, 0);
+            if (at0 >= (uint32_t)p.seed_cap) break;
+            const uint32_t at = at0 + __popcll(m & ((1ull << lane) - 1ull));
+            if (ok && at < (uint32_t)p.seed_cap) p.seed_cand[q * p.seed_cap + at] = id;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) p.seed_cnt[q] = s_seed < (uint32_t)p.seed_cap ? (int32_t)s_seed : p.seed_cap;
+}
+
+void launch_fill_lists(const ProbeParams &p, int64_t nq, hipStream_t stream)
+{
+    if (nq > 0) hipLaunchKernelGGL(k_fill_lists, dim3((unsigned)nq), dim3(256), 0, stream, p);
 }
 
 void launch_probe(int mode, const ProbeParams &p, int64_t nq, hipStream_t stream)
@@ -1206,7 +1263,7 @@ void launch_tile_maxnorm(uint4 *tiles, int64_t ntiles, const int32_t *ids, const
 // first queries) and once per further chunk; the other waves of the SIMD fill those waits.
 // RB*16 rows per tile: 64 measured best on gfx950 (32-row tiles double the per-unit work and
 // were 1.9x slower in spite of the higher occupancy).
-constexpr int ls16_waves(int ks, int rb) { return rb == 2 ? (ks >= 8 ? 2 : 4) : (ks >= 8 ? 2 : 3); }
+constexpr int ls16_waves(int ks, int rb) { return rb == 2 ? (ks >= 8 ? 2 : 4) : (ks >= 8 ? 2 : LS16_WAVES4); }
 
 template <int KS, int METRIC, int RB>
 __global__ __launch_bounds__(256, ls16_waves(KS, RB)) void k_leafscan_f16(LeafScanParams p, const uint16_t *__restrict__ Q16,
@@ -1222,6 +1279,10 @@ __global__ __launch_bounds__(256, ls16_waves(KS, RB)) void k_leafscan_f16(LeafSc
     uint32_t u = (uint32_t)p.unit_begin + blockIdx.x * 4u + (uint32_t)wave;
     if (u >= nunits) return;
     const int i16 = lane & 15, g = lane >> 4;
+    // Query j of a 16-query chunk sits in MFMA row 4*(j%4) + j/4, so that the accumulator register
+    // r of every lane belongs to queries 4r..4r+3 and a chunk of n queries needs only its first
+    // ceil(n/4) registers tested; jq = the chunk position this lane's row holds.
+    const uint32_t jq = 4u * (uint32_t)(i16 & 3) + (uint32_t)(i16 >> 2);
     constexpr int STRIDE = KS * 32;                       // fp16 elements per padded row
     const unsigned long long lt = (1ull << lane) - 1ull;
     const unsigned long long gmask = 0xffffull << (16 * g);
@@ -1251,8 +1312,8 @@ __global__ __launch_bounds__(256, ls16_waves(KS, RB)) void k_leafscan_f16(LeafSc
             if (!(v >= row_lo && v < row_hi)) v = -1;
             id[rb] = v;
         }
-        qs = (uint32_t)i16 < nq ? p.leaf_queries[U.z + i16] : -1;
-        qsn = 16u + i16 < nq ? p.leaf_queries[U.z + 16u + i16] : -1;
+        qs = jq < nq ? p.leaf_queries[U.z + jq] : -1;
+        qsn = 16u + jq < nq ? p.leaf_queries[U.z + 16u + jq] : -1;
     };
 
     uint4 U0 = desc(u), U1 = desc(u + W);
@@ -1263,8 +1324,10 @@ __global__ __launch_bounds__(256, ls16_waves(KS, RB)) void k_leafscan_f16(LeafSc
         // this unit's rows
         f16x8 xb[RB][KS];
         float J[RB], xn[RB];                              // the row's share of the threshold; |x~|^2
+        const uint32_t rows = U0.y & 0xffu;               // 16-row blocks past the tile's end are skipped throughout
 #pragma unroll
         for (int rb = 0; rb < RB; rb++) {
+            if (rb * 16u >= rows && rb > 0) continue;
             const size_t at = (size_t)(id0[rb] >= 0 ? id0[rb] - row_lo : 0);
             const uint16_t *row = B16 + at * STRIDE + 8 * g;
 #pragma unroll
@@ -1300,7 +1363,7 @@ __global__ __launch_bounds__(256, ls16_waves(KS, RB)) void k_leafscan_f16(LeafSc
             const int32_t qcur = qsc;
             // query indices two chunks ahead
             qsc = qsn;
-            qsn = c + 32u + i16 < nq ? p.leaf_queries[lq0 + c + 32u + i16] : -1;
+            qsn = c + 32u + jq < nq ? p.leaf_queries[lq0 + c + 32u + jq] : -1;
 
             // Per-slot thresholds on d = q~.x~ - J(row); lane i16 of every 16-lane group holds query slot i16.
             //   l2:  | |q~ - x~| - |q - x| | <= |q - q~| + |x - x~| =: eta, so forward when |q~ - x~|^2 could be
@@ -1333,12 +1396,14 @@ __global__ __launch_bounds__(256, ls16_waves(KS, RB)) void k_leafscan_f16(LeafSc
             }
             f32x4 acc[RB];
 #pragma unroll
-            for (int rb = 0; rb < RB; rb++) acc[rb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int rb = 0; rb < RB; rb++) {
+                acc[rb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (rb * 16u >= rows && rb > 0) continue;
 #pragma unroll
-            for (int t = 0; t < KS; t++)
-#pragma unroll
-                for (int rb = 0; rb < RB; rb++) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qa[t], xb[rb][t], acc[rb], 0, 0, 0);
-            // lane l holds q~(4g + r) . x~(rb*16 + i16) in acc[rb][r]
+                for (int t = 0; t < KS; t++) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qa[t], xb[rb][t], acc[rb], 0, 0, 0);
+            }
+            // lane l holds q~(MFMA row 4g + r) . x~(rb*16 + i16) in acc[rb][r]
+            const uint32_t nslot = min(16u, nq - c);       // queries in this chunk
             if (p.debug) {                                // ablation runs: loads and products only
                 float t = 0.f;
 #pragma unroll
@@ -1348,6 +1413,7 @@ __global__ __launch_bounds__(256, ls16_waves(KS, RB)) void k_leafscan_f16(LeafSc
             }
 #pragma unroll
             for (int r = 0; r < 4; r++) {
+                if (4u * r >= nslot) break;
                 const int slot = 4 * g + r;
                 const float4 sc = s_slot[wave][slot];
                 float d[RB];
@@ -1358,6 +1424,7 @@ __global__ __launch_bounds__(256, ls16_waves(KS, RB)) void k_leafscan_f16(LeafSc
                 for (int rb = 0; rb < RB; rb++) {
                     d[rb] = acc[rb][r] - J[rb];
                     pass[rb] = d[rb] >= sc.x;
+                    if (rb * 16u >= rows && rb > 0) { pass[rb] = false; continue; }
                     many |= __ballot(pass[rb]);
                     if (METRIC == 1) tight += __popcll(__ballot(d[rb] >= sc.y) & gmask);
                 }

@@ -403,3 +403,19 @@ def test_bucket_major_many_queries_per_bucket_and_repeated_batches():
         assert fast.stats()["last_path"] == 1
         si, ss = slow.query_topk(pick[:nq], Q[:nq], steps=1, k=10)
         assert np.array_equal(fi, si) and np.array_equal(fs, ss, equal_nan=True)
+
+
+@pytest.mark.gpu
+def test_bucket_major_truncated_bucket_lists_walk_again(monkeypatch):
+    # the first probe pass remembers each query's buckets up to a cap; past it the lists are
+    # filled by a second walk.  Same answer either way.
+    params, X, Q, pick = make_problem(n=8000, nq=60, bucket_overflow=60, n_clusters=6)
+    slow = DpfIndex(dict(params, flags=2), metric="l2")
+    slow.fit(X)
+    want = slow.query_topk(pick, Q, steps=1, k=10)
+    monkeypatch.setenv("DPF_Q_LEAF_CAP", "3")
+    fast = DpfIndex(params, metric="l2")
+    fast.fit(X)
+    got = fast.query_topk(pick, Q, steps=1, k=10)
+    assert fast.stats()["last_path"] == 1
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1], equal_nan=True)
