@@ -603,7 +603,6 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     launch_hash(ix->cfg.dtype, qpad, qstride, nq, ix->hp, ix->ws_hashes.as<int32_t>(), ix->ws_parts.as<int32_t>(), stream);
     if (ix->profiling) HIPCHECK(ix, hipEventRecord(ix->ev[1], stream));
     HIPCHECK(ix, hipMemsetAsync(ix->ws_lq_cnt.p, 0, (size_t)(nl + 1) * 4, stream));
-    HIPCHECK(ix, hipMemsetAsync(ix->ws_lq_cursor.p, 0, (size_t)(nl + 1) * 4, stream));
     HIPCHECK(ix, hipMemsetAsync(ix->ws_emit_cnt.p, 0, (size_t)nq * 4, stream));
     HIPCHECK(ix, hipMemsetAsync(ix->ws_flag.p, 0, 16, stream));
     ProbeParams pp;
@@ -617,9 +616,9 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
         const int64_t most = (int64_t)L * 28 * nsub;          // every probe in a bucket of its own
         pp.q_leaf_cap = (int32_t)std::min<int64_t>(most, 4096);
         if (const char *e = getenv("DPF_Q_LEAF_CAP")) pp.q_leaf_cap = std::max(1, atoi(e));   // tests: force truncation
-        HIPCHECK(ix, ix->ws_q_leaves.ensure((size_t)nq * pp.q_leaf_cap * 4));
+        HIPCHECK(ix, ix->ws_q_leaves.ensure((size_t)nq * pp.q_leaf_cap * 8));
         HIPCHECK(ix, ix->ws_q_leaf_cnt.ensure((size_t)nq * 4));
-        pp.q_leaves = ix->ws_q_leaves.as<uint32_t>();
+        pp.q_leaves = ix->ws_q_leaves.as<uint2>();
         pp.q_leaf_cnt = ix->ws_q_leaf_cnt.as<int32_t>();
         pp.q_leaf_overflow = ix->ws_flag.as<int32_t>() + 1;
     }
@@ -662,7 +661,10 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     pp.seed_cand = ix->ws_seed_cand.as<int32_t>();
     pp.seed_cnt = ix->ws_seed_cnt.as<int32_t>();
     pp.seed_cap = SEED_CAP;
-    if (lists_truncated) launch_probe(2, pp, nq, stream);
+    if (lists_truncated) {
+        HIPCHECK(ix, hipMemsetAsync(ix->ws_lq_cursor.p, 0, (size_t)(nl + 1) * 4, stream));
+        launch_probe(2, pp, nq, stream);
+    }
     else launch_fill_lists(pp, nq, stream);
     if (ix->profiling) HIPCHECK(ix, hipEventRecord(ix->ev[2], stream));
 

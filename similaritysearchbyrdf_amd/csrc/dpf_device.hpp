@@ -45,7 +45,8 @@ struct ProbeParams {
     int64_t *bound;           // [nq] min(raw, rows in shard)
     unsigned long long *short_hash_events;
     uint32_t *lq_cnt;         // [num_leaves] optional: (query, bucket) incidence histogram
-    uint32_t *q_leaves;       // [nq][q_leaf_cap] optional: the distinct non-empty buckets each query reached
+    uint2 *q_leaves;          // [nq][q_leaf_cap] optional: the distinct non-empty buckets each query reached,
+                              // with the query's place in the bucket's list
     int32_t *q_leaf_cnt;      // [nq] their number (may exceed q_leaf_cap: list truncated)
     int32_t q_leaf_cap;
     int32_t *q_leaf_overflow; // set to 1 when any list was truncated

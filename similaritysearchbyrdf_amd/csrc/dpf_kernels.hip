@@ -332,82 +332,109 @@ __global__ __launch_bounds__(1024) void k_probe(ProbeParams p)
             }
             const uint32_t seg = h >> p.bucket_bits;
             const uint32_t *roots = p.roots + ((size_t)t * P) * p.seg + seg;
-            int pair0 = -1, pair1 = -1;
-            for (int s = 0; s <= P; s++) {
-                if (s < P && __popc((uint32_t)(s ^ part)) <= p.steps) {
-                    if (pair0 < 0) pair0 = s; else pair1 = s;
-                }
-                if ((pair1 >= 0) || (s == P && pair0 >= 0)) {
-                    const int sub = half ? pair1 : pair0;
-                    // lane 31 of each half walks the unflipped hash: it is not a probe (RDT:753-758),
-                    // it only names the query's own bucket for the collapse below
-                    uint32_t leaf = NO_LEAF;
-                    if (sub >= 0 && (i < nprobe || i == 31))
-                        leaf = walk(p.dnodes, roots[(size_t)sub * p.seg], i == 31 ? h : h ^ (1u << i), p.max_level, p.nbits, p.dns);
-                    // Collapse probes that reached the same bucket (same sub-index only: buckets of
-                    // different sub-indexes are disjoint).  A flipped bit either changes the path at its
-                    // level - then the probe ends in a subtree no other probe enters - or it lies below
-                    // the level where the path ends (or in bits the trie does not use) and the probe ends
-                    // in the query's own bucket.  So only the own bucket can be reached more than once.
-                    const uint32_t own = __shfl(leaf, (lane & 32) + 31);
-                    if (i == 31) leaf = NO_LEAF;
-                    const unsigned long long same = __ballot(leaf != NO_LEAF && leaf == own) >> (lane & 32);
-                    if (leaf == own && (same & ((1ull << i) - 1ull) & 0xffffffffull)) leaf = NO_LEAF;
-                    uint32_t beg = 0, end = 0;
-                    if (leaf != NO_LEAF) { beg = p.leaf_off[leaf]; end = p.leaf_off[leaf + 1]; }
-                    if (MODE == 0) {
-                        raw_local += end - beg;
-                        if (p.lq_cnt && end > beg) {
-                            atomicAdd(&p.lq_cnt[leaf], 1u);
-                            if (p.q_leaves) {
-                                const uint32_t pos = atomicAdd(&s_nleaf, 1u);
-                                if (pos < (uint32_t)p.q_leaf_cap) p.q_leaves[q * p.q_leaf_cap + pos] = leaf;
-                            }
+            // what is done with one lane's bucket (every lane calls it, with NO_LEAF when it has none)
+            auto take = [&](uint32_t leaf) {
+                uint32_t beg = 0, end = 0;
+                if (leaf != NO_LEAF) { beg = p.leaf_off[leaf]; end = p.leaf_off[leaf + 1]; }
+                if (MODE == 0) {
+                    raw_local += end - beg;
+                    if (p.lq_cnt && end > beg) {
+                        // the old count is this query's place in the bucket's list
+                        const uint32_t place = atomicAdd(&p.lq_cnt[leaf], 1u);
+                        if (p.q_leaves) {
+                            const uint32_t pos = atomicAdd(&s_nleaf, 1u);
+                            if (pos < (uint32_t)p.q_leaf_cap) p.q_leaves[q * p.q_leaf_cap + pos] = make_uint2(leaf, place);
                         }
-                    } else if (MODE == 2) {
-                        if (end > beg) {
-                            const uint32_t pos = atomicAdd(&p.lq_cursor[leaf], 1u);
-                            p.leaf_queries[p.lq_off[leaf] + pos] = (int32_t)q;
+                    }
+                } else if (MODE == 2) {
+                    if (end > beg) {
+                        const uint32_t pos = atomicAdd(&p.lq_cursor[leaf], 1u);
+                        p.leaf_queries[p.lq_off[leaf] + pos] = (int32_t)q;
+                    }
+                    // seed sample: ids of the first buckets any wave reaches, up to seed_cap
+                    // (duplicates across tables are harmless: the exact rerank keeps one)
+                    unsigned long long mask = __ballot(end > beg);
+                    while (mask && s_seed < (uint32_t)p.seed_cap) {
+                        const int src = __ffsll((long long)mask) - 1;
+                        mask &= mask - 1;
+                        const uint32_t b = __shfl(beg, src), e = __shfl(end, src);
+                        for (uint32_t k0 = b; k0 < e; k0 += 64) {
+                            const uint32_t k = k0 + lane;
+                            const int32_t id = k < e ? p.ids[k] : -1;
+                            const bool ok = k < e && id >= p.row_begin && id < p.row_end &&
+                                            !self_excluded(id, qid, p.exclude_self);
+                            const unsigned long long m = __ballot(ok);
+                            if (m == 0) continue;
+                            uint32_t at0 = 0;
+                            if (lane == 0) at0 = atomicAdd(&s_seed, (uint32_t)__popcll(m));
+                            at0 = __shfl(at0, 0);
+                            if (at0 >= (uint32_t)p.seed_cap) break;
+                            const uint32_t at = at0 + __popcll(m & ((1ull << lane) - 1ull));
+                            if (ok && at < (uint32_t)p.seed_cap) p.seed_cand[q * p.seed_cap + at] = id;
                         }
-                        // seed sample: ids of the first buckets any wave reaches, up to seed_cap
-                        // (duplicates across tables are harmless: the exact rerank keeps one)
-                        unsigned long long mask = __ballot(end > beg);
-                        while (mask && s_seed < (uint32_t)p.seed_cap) {
-                            const int src = __ffsll((long long)mask) - 1;
-                            mask &= mask - 1;
-                            const uint32_t b = __shfl(beg, src), e = __shfl(end, src);
-                            for (uint32_t k0 = b; k0 < e; k0 += 64) {
-                                const uint32_t k = k0 + lane;
-                                const int32_t id = k < e ? p.ids[k] : -1;
-                                const bool ok = k < e && id >= p.row_begin && id < p.row_end &&
-                                                !self_excluded(id, qid, p.exclude_self);
-                                const unsigned long long m = __ballot(ok);
-                                if (m == 0) continue;
-                                uint32_t at0 = 0;
-                                if (lane == 0) at0 = atomicAdd(&s_seed, (uint32_t)__popcll(m));
-                                at0 = __shfl(at0, 0);
-                                if (at0 >= (uint32_t)p.seed_cap) break;
-                                const uint32_t at = at0 + __popcll(m & ((1ull << lane) - 1ull));
-                                if (ok && at < (uint32_t)p.seed_cap) p.seed_cand[q * p.seed_cap + at] = id;
-                            }
-                        }
-                    } else {
-                        unsigned long long mask = __ballot(leaf != NO_LEAF);
-                        while (mask) {
-                            const int src = __ffsll((long long)mask) - 1;
-                            mask &= mask - 1;
-                            const uint32_t b = __shfl(beg, src), e = __shfl(end, src);
-                            for (uint32_t k = b + lane; k < e; k += 64) {
-                                const int32_t id = p.ids[k];
-                                if (id >= lo && id < hi && !self_excluded(id, qid, p.exclude_self)) {
-                                    const uint32_t bit = (uint32_t)(id - lo);
-                                    atomicOr(&lds[bit >> 5], 1u << (bit & 31));
-                                }
+                    }
+                } else {
+                    unsigned long long mask = __ballot(leaf != NO_LEAF);
+                    while (mask) {
+                        const int src = __ffsll((long long)mask) - 1;
+                        mask &= mask - 1;
+                        const uint32_t b = __shfl(beg, src), e = __shfl(end, src);
+                        for (uint32_t k = b + lane; k < e; k += 64) {
+                            const int32_t id = p.ids[k];
+                            if (id >= lo && id < hi && !self_excluded(id, qid, p.exclude_self)) {
+                                const uint32_t bit = (uint32_t)(id - lo);
+                                atomicOr(&lds[bit >> 5], 1u << (bit & 31));
                             }
                         }
                     }
-                    pair0 = pair1 = -1;
                 }
+            };
+            // the sub-indexes within `steps` bit flips of the query's own, four per round: the lower
+            // half-wave walks the first and third, the upper the second and fourth, each lane two
+            // walks at a time so that their dependent loads overlap
+            uint32_t submask = 0;
+            for (int s = 0; s < P; s++)
+                if (__popc((uint32_t)(s ^ part)) <= p.steps) submask |= 1u << s;
+            // lane 31 of each half walks the unflipped hash: it is not a probe (RDT:753-758),
+            // it only names the query's own bucket for the collapse below
+            const bool act = i < nprobe || i == 31;
+            const uint32_t key = i == 31 ? h : h ^ (1u << i);
+            while (submask) {
+                int sub[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    sub[k] = -1;
+                    if (submask) { sub[k] = __ffs((int)submask) - 1; submask &= submask - 1; }
+                }
+                const int sA = half ? sub[1] : sub[0], sB = half ? sub[3] : sub[2];
+                uint32_t leaf[2] = {NO_LEAF, NO_LEAF}, node[2];
+                node[0] = (act && sA >= 0) ? roots[(size_t)sA * p.seg] : 0u;
+                node[1] = (act && sB >= 0) ? roots[(size_t)sB * p.seg] : 0u;
+                for (int level = p.max_level; level >= 0 && (node[0] | node[1]); --level) {
+                    const uint32_t slot = (key >> (level * p.nbits)) & (uint32_t)(p.dns - 1);
+                    uint32_t w[2];
+#pragma unroll
+                    for (int k = 0; k < 2; k++) w[k] = node[k] ? p.dnodes[(size_t)node[k] * p.dns + slot] : 0u;
+#pragma unroll
+                    for (int k = 0; k < 2; k++) {
+                        if (w[k] & 1u) { leaf[k] = w[k] >> 1; node[k] = 0; }
+                        else node[k] = w[k] >> 1;
+                    }
+                }
+                // Collapse probes that reached the same bucket (same sub-index only: buckets of
+                // different sub-indexes are disjoint).  A flipped bit either changes the path at its
+                // level - then the probe ends in a subtree no other probe enters - or it lies below
+                // the level where the path ends (or in bits the trie does not use) and the probe ends
+                // in the query's own bucket.  So only the own bucket can be reached more than once.
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    const uint32_t own = __shfl(leaf[k], (lane & 32) + 31);
+                    if (i == 31) leaf[k] = NO_LEAF;
+                    const unsigned long long same = __ballot(leaf[k] != NO_LEAF && leaf[k] == own) >> (lane & 32);
+                    if (leaf[k] == own && (same & ((1ull << i) - 1ull) & 0xffffffffull)) leaf[k] = NO_LEAF;
+                }
+                take(leaf[0]);
+                take(leaf[1]);
             }
         }
         if (MODE != 1) break;
@@ -474,7 +501,7 @@ __global__ __launch_bounds__(1024) void k_probe(ProbeParams p)
 }
 
 // k_fill_lists: what k_probe<2> does, from the bucket lists k_probe<0> recorded instead of a
-// second walk of the forest: append the query to every bucket it reached, copy the ids of the
+// second walk of the forest: write the query into its place in every bucket's list, copy the ids of the
 // first buckets into its seed sample.  Only launched when no query's list was truncated.
 __global__ __launch_bounds__(256) void k_fill_lists(ProbeParams p)
 {
@@ -485,14 +512,13 @@ __global__ __launch_bounds__(256) void k_fill_lists(ProbeParams p)
     const int32_t qid = p.qids ? p.qids[q] : -1;
     if (tid == 0) s_seed = 0;
     __syncthreads();
-    const uint32_t *mine = p.q_leaves + q * p.q_leaf_cap;
+    const uint2 *mine = p.q_leaves + q * p.q_leaf_cap;
     for (int j = tid; j < n; j += 256) {
-        const uint32_t leaf = mine[j];
-        const uint32_t pos = atomicAdd(&p.lq_cursor[leaf], 1u);
-        p.leaf_queries[p.lq_off[leaf] + pos] = (int32_t)q;
+        const uint2 lp = mine[j];                         // {bucket, place in the bucket's list}
+        p.leaf_queries[p.lq_off[lp.x] + lp.y] = (int32_t)q;
     }
     for (int j = wave; j < n && s_seed < (uint32_t)p.seed_cap; j += 4) {
-        const uint32_t leaf = mine[j];
+        const uint32_t leaf = mine[j].x;
         const uint32_t b = p.leaf_off[leaf], e = p.leaf_off[leaf + 1];
         for (uint32_t k0 = b; k0 < e; k0 += 64) {
             const uint32_t k = k0 + lane;
