@@ -176,7 +176,8 @@ def main():
     d_sc = torch.empty((nq, k), dtype=torch.float64, device=dev)
 
     def step():
-        # hash -> probe -> dedupe -> rerank on this rank's shard; with N > 1 one all-gather per
+        # hash -> probe -> scan -> rerank on this rank's shard (of the tables, or of the rows for a
+        # single-table forest); with N > 1 one all-gather per
         # array of the partial top-k lists and the merge kernel
         sharded.query_topk(dqid, dQ, steps, k, d_ids, d_sc, torch.cuda.current_stream().cuda_stream)
 
@@ -265,7 +266,7 @@ def main():
                                    "bucket overflow %d, %d-step search, top-%d by %s" % (
                                        args.workload, X.shape[1], n, nq, ix.L, ix.pb, params["bucket_overflow"],
                                        steps, k, args.metric),
-                       "global_batch": nq, "parallelism": "rows%d" % world,
+                       "global_batch": nq, "parallelism": "%s%d" % (sharded.mode, world),
                        "recall_at_10": recall, "fit_seconds": round(fit_s, 2),
                        "rerank_path": "bucket-major fp16 scan + exact fp64 rerank" if st["last_path"] == 1 else "gather",
                        "ids_visited_per_query_on_rank0": st["last_raw_candidates"] / nq,

@@ -73,6 +73,8 @@ typedef struct dpf_config {
                                  vectors at this boundary and in HBM              */
     int32_t device;           /* HIP device ordinal                               */
     int32_t flags;            /* DPF_FLAG_* */
+    int32_t table_begin;      /* table shard: this handle probes only tables          */
+    int32_t table_end;        /* table_begin <= t < table_end; table_end <= 0 = all L */
     int64_t row_begin;        /* rerank shard: this handle scores only candidates  */
     int64_t row_end;          /* with row_begin <= id < row_end; row_end < 0 = all */
 } dpf_config;

@@ -24,7 +24,8 @@ class DpfConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "family", "dim", "num_functions", "num_tables", "chain_length", "partition_bits",
         "bucket_bits", "dir_node_size", "bucket_overflow", "type_of_index", "exclude_self",
-        "metric", "top_k", "dtype", "device", "flags")] + [("row_begin", C.c_int64), ("row_end", C.c_int64)]
+        "metric", "top_k", "dtype", "device", "flags", "table_begin", "table_end")] + [
+        ("row_begin", C.c_int64), ("row_end", C.c_int64)]
 
 
 class DpfStats(C.Structure):
@@ -125,11 +126,12 @@ class DpfIndex:
     params: dict with fns [F,d], chain_fn [L,m], optional b/w [F], part_fns
     [L,pb,32], part_b/part_w [L,pb], family, partition_bits, bucket_bits,
     dir_node_size, bucket_overflow, type_of_index, exclude_self,
-    sampling_index; plus metric, top_k, dtype, device, row_begin, row_end.
+    sampling_index; plus metric, top_k, dtype, device, row_begin, row_end (row shard),
+    table_begin, table_end (table shard).
     """
 
     def __init__(self, params, metric="dot", top_k=10, dtype=np.float32, device=0,
-                 row_begin=0, row_end=-1):
+                 row_begin=0, row_end=-1, table_begin=0, table_end=0):
         self.L_ = lib()
         p = params
         fns = _f64(p["fns"])
@@ -144,7 +146,8 @@ class DpfIndex:
             dir_node_size=int(p.get("dir_node_size", 32)), bucket_overflow=int(p.get("bucket_overflow", 500)),
             type_of_index=TYPE_OF_INDEX[p.get("type_of_index", "original")],
             exclude_self=SELF[p.get("exclude_self", "compat")], metric=METRIC[metric], top_k=top_k,
-            dtype=DTYPE[self.np_dtype], device=device, flags=int(p.get('flags', 0)), row_begin=row_begin, row_end=row_end)
+            dtype=DTYPE[self.np_dtype], device=device, flags=int(p.get('flags', 0)), table_begin=table_begin, table_end=table_end,
+            row_begin=row_begin, row_end=row_end)
         self.dim, self.L, self.pb, self.top_k = d, Lt, pb, top_k
         self.h = C.c_void_p()
         rc = self.L_.dpf_create(C.byref(self.cfg), C.byref(self.h))

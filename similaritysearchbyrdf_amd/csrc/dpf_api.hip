@@ -147,6 +147,8 @@ extern "C" int dpf_create(const dpf_config *cfg, dpf_index **out)
     else if (cfg->metric != DPF_METRIC_DOT && cfg->metric != DPF_METRIC_L2) why = "metric must be dot or l2";
     else if (cfg->type_of_index < 0 || cfg->type_of_index > 3) why = "unknown type_of_index";
     else if (cfg->exclude_self < 0 || cfg->exclude_self > 2) why = "unknown exclude_self mode";
+    else if (cfg->table_begin < 0 || cfg->table_begin > cfg->num_tables || cfg->table_end > cfg->num_tables ||
+             (cfg->table_end > 0 && cfg->table_end < cfg->table_begin)) why = "table shard outside [0, num_tables]";
     if (!why.empty()) { delete ix; return fail(nullptr, DPF_EINVAL, "dpf_create: " + why); }
     if (cfg->family == DPF_FAMILY_PSTABLE && cfg->chain_length > 1024) { delete ix; return fail(nullptr, DPF_EINVAL, "dpf_create: chain_length too large"); }
     ix->elem = cfg->dtype == DPF_F32 ? 4 : 8;
@@ -491,6 +493,8 @@ static void fill_probe_params(dpf_index *ix, ProbeParams &pp, const int32_t *d_q
     pp.L = g.num_tables; pp.pb = g.partition_bits; pp.bucket_bits = g.bucket_bits; pp.seg = g.seg;
     pp.nbits = g.nbits; pp.dns = g.dir_node_size; pp.max_level = g.max_level;
     pp.steps = steps; pp.exclude_self = ix->cfg.exclude_self;
+    pp.t_begin = ix->cfg.table_begin;
+    pp.t_end = ix->cfg.table_end <= 0 ? g.num_tables : ix->cfg.table_end;
     pp.qids = d_qids;
     pp.hashes = ix->ws_hashes.as<int32_t>();
     pp.parts = ix->ws_parts.as<int32_t>();

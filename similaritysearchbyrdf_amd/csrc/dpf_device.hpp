@@ -34,6 +34,7 @@ struct ProbeParams {
     const int32_t *ids;       // bucket contents
     int32_t L, pb, bucket_bits, seg, nbits, dns, max_level;
     int32_t steps, exclude_self;
+    int32_t t_begin, t_end;   // table shard probed by this handle
     // query batch
     const int32_t *qids;      // [nq] or nullptr
     const int32_t *hashes;    // [nq][L]

@@ -321,7 +321,7 @@ __global__ __launch_bounds__(1024) void k_probe(ProbeParams p)
         }
         __syncthreads();
 
-        for (int t = wave; t < p.L; t += nwaves) {
+        for (int t = p.t_begin + wave; t < p.t_end; t += nwaves) {
             const uint32_t h = (uint32_t)p.hashes[q * p.L + t];
             const int part = p.parts[q * p.L + t];
             // RDT:753: 32 - numberOfLeadingZeros(h) - 4 probes; negative for 0 <= h < 8
@@ -1792,8 +1792,13 @@ __global__ void k_merge_topk(const int32_t *__restrict__ in_ids, const double *_
             const double sc = in_scores[at];
             if (best < 0 || better<METRIC>(sc, id, bs, bi)) { best = s; bs = sc; bi = id; }
         }
-        if (best < 0) { out_ids[q * k + e] = -1; out_scores[q * k + e] = nan(""); }
-        else { out_ids[q * k + e] = bi; out_scores[q * k + e] = bs; head[best]++; }
+        if (best < 0) { out_ids[q * k + e] = -1; out_scores[q * k + e] = nan(""); continue; }
+        out_ids[q * k + e] = bi;
+        out_scores[q * k + e] = bs;
+        // lists of table shards can hold the same row (same exact score): it sits at the head of
+        // every list that has it, and is taken once
+        for (int s = 0; s < parts; s++)
+            if (head[s] < k && in_ids[((int64_t)s * nq + q) * k + head[s]] == bi) head[s]++;
     }
 }
 

@@ -1,6 +1,7 @@
-"""World-size-2 rehearsal of the row-sharded query on CPU (gloo): shard bounds, the
-all-gather exchange and the merge rule, with the oracle standing in for each
-rank's device stage.  The merged lists must equal the unsharded oracle's."""
+"""World-size-2 rehearsal of the sharded query on CPU (gloo), row shards and table
+shards: shard bounds, the all-gather exchange and the merge rule, with the oracle
+standing in for each rank's device stage.  The merged lists must equal the
+unsharded oracle's."""
 import os
 import sys
 
@@ -20,7 +21,7 @@ def _worker(rank, world, port, ret):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from oracle import oracle as O
-        from similaritysearchbyrdf_amd.dist import shard_bounds, exchange, merge_topk_host
+        from similaritysearchbyrdf_amd.dist import shard_bounds, table_bounds, num_tables_of, exchange, merge_topk_host
         from tests.common import make_problem
         params, X, Q, pick = make_problem(n=3001, nq=21, bucket_overflow=30, table_num=2, permutation_num=2)
         n = X.shape[0]
@@ -46,6 +47,26 @@ def _worker(rank, world, port, ret):
             want_ids, want_sc = orc.topk(Q64, off, ids, k=10, metric=metric, threads=2)
             assert np.array_equal(m_ids, want_ids), metric
             assert np.array_equal(np.nan_to_num(m_sc), np.nan_to_num(want_sc)), metric
+        # table shards: this rank's stage is the union of the candidate lists of ITS tables
+        # (RandomDrawTreeMap.java:742-797 per table, Set union of DensevectorRDFInit.scala:420,428)
+        L = num_tables_of(params)
+        t_lo, t_hi = table_bounds(L, world, rank)
+        loc, loc_off = [], [0]
+        for q in range(len(pick)):
+            per_table = [orc.get_similar(t, int(pick[q]), Q64[q], 1) for t in range(t_lo, t_hi)]
+            c = np.unique(np.concatenate(per_table)) if per_table else np.zeros(0, dtype=np.int32)
+            loc.append(c.astype(np.int32))
+            loc_off.append(loc_off[-1] + len(c))
+        loc_ids = np.concatenate(loc) if loc else np.zeros(0, dtype=np.int32)
+        for metric in ("l2", "dot"):
+            pi, ps = orc.topk(Q64, np.asarray(loc_off), loc_ids, k=10, metric=metric, threads=2)
+            g_ids, g_sc = exchange(torch.from_numpy(pi), torch.from_numpy(ps))
+            m_ids, m_sc = merge_topk_host(g_ids.numpy(), g_sc.numpy(), metric)
+            want_ids, want_sc = orc.topk(Q64, off, ids, k=10, metric=metric, threads=2)
+            assert np.array_equal(m_ids, want_ids), ("tables", metric)
+            assert np.array_equal(np.nan_to_num(m_sc), np.nan_to_num(want_sc)), ("tables", metric)
+        tb = [table_bounds(L, world, r) for r in range(world)]
+        assert tb[0][0] == 0 and tb[-1][1] == L and all(tb[i][1] == tb[i + 1][0] for i in range(world - 1))
         # shard bounds tile the id space exactly
         b = [shard_bounds(n, world, r) for r in range(world)]
         assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(world - 1))
@@ -78,3 +99,8 @@ def test_shard_bounds_edge_cases():
     assert mi.tolist() == [[2, 5, 7]] and ms.tolist() == [[1.0, 1.0, 2.0]]
     mi, ms = merge_topk_host(ids, sc, "dot")
     assert mi.tolist() == [[9, 7, 2]]
+    # an id present in two lists (table shards) is taken once
+    ids = np.array([[[5, 9, 11]], [[5, 7, 9]]], dtype=np.int32)
+    sc = np.array([[[1.0, 3.0, 4.0]], [[1.0, 2.0, 3.0]]])
+    mi, ms = merge_topk_host(ids, sc, "l2")
+    assert mi.tolist() == [[5, 7, 9]] and ms.tolist() == [[1.0, 2.0, 3.0]]

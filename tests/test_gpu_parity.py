@@ -419,3 +419,40 @@ def test_bucket_major_truncated_bucket_lists_walk_again(monkeypatch):
     got = fast.query_topk(pick, Q, steps=1, k=10)
     assert fast.stats()["last_path"] == 1
     assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1], equal_nan=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("metric", ["l2", "dot"])
+def test_table_shards_and_merge(metric):
+    # every handle holds everything but probes only its tables; per-handle candidate sets are the
+    # union over those tables, and the merged top-k (an id found by several handles taken once)
+    # is the unsharded answer
+    import torch
+    params, X, Q, pick = make_problem(n=6000, nq=40, bucket_overflow=50, table_num=3, permutation_num=2)
+    orc = O.OracleIndex(params)
+    orc.fit(X.astype(np.float64))
+    Q64 = Q.astype(np.float64)
+    off, ids = orc.query_batch(pick, Q64, steps=1)
+    want = orc.topk(Q64, off, ids, k=10, metric=metric)
+    bounds = [(0, 2), (2, 3), (3, 6)]
+    parts_ids, parts_sc = [], []
+    for lo, hi in bounds:
+        g = DpfIndex(params, metric=metric, table_begin=lo, table_end=hi)
+        g.fit(X)
+        so, si = g.query_batch(pick, Q, steps=1)
+        for q in range(40):
+            w = np.unique(np.concatenate([orc.get_similar(t, int(pick[q]), Q64[q], 1) for t in range(lo, hi)]))
+            assert np.array_equal(si[so[q]:so[q + 1]], w)
+        pi, ps = g.query_topk(pick, Q, steps=1, k=10)
+        parts_ids.append(pi)
+        parts_sc.append(ps)
+    dev = torch.device("cuda:0")
+    t_ids = torch.from_numpy(np.stack(parts_ids)).to(dev)
+    t_sc = torch.from_numpy(np.stack(parts_sc)).to(dev)
+    o_ids = torch.empty((40, 10), dtype=torch.int32, device=dev)
+    o_sc = torch.empty((40, 10), dtype=torch.float64, device=dev)
+    g.merge_topk_device(t_ids.data_ptr(), t_sc.data_ptr(), 3, 40, 10, o_ids.data_ptr(), o_sc.data_ptr())
+    torch.cuda.synchronize()
+    assert_topk_equal(o_ids.cpu().numpy(), o_sc.cpu().numpy(), want[0], want[1])
+    with pytest.raises(Exception):
+        DpfIndex(params, metric=metric, table_begin=4, table_end=9)
