@@ -155,13 +155,26 @@ int dpf_query_topk_device(dpf_index *ix, const int32_t *d_qids, const void *d_Q,
 int dpf_rerank(dpf_index *ix, const void *Q, int64_t nq, const int64_t *cand_offsets,
                const int32_t *cand_ids, int32_t k, int32_t *ids, double *scores);
 
-/* Merge `parts` partial top-k lists per query (row-sharded handles on several
- * devices, gathered by the caller): in_ids/in_scores [parts][nq][k] device
+/* Merge `parts` partial top-k lists per query (row- or table-sharded handles on
+ * several devices, gathered by the caller; an id present in several lists is
+ * taken once): in_ids/in_scores [parts][nq][k] device
  * memory -> d_ids/d_scores [nq][k].  No counterpart in the reference, which is
  * a single process. */
 int dpf_merge_topk_device(dpf_index *ix, const int32_t *in_ids, const double *in_scores,
                           int32_t parts, int64_t nq, int32_t k, int32_t *d_ids, double *d_scores,
                           void *stream);
+
+/* A fitted handle to one file and back: configuration, hash family and
+ * partitioner, the hashes of every id and the resident rows (the forest is
+ * rebuilt from the hashes on load; results after a load are those of the handle
+ * that was saved).  Stands where the reference persists its tables to disk
+ * (RandomDrawTreeMap.java:2713-2773, the StoreAppend files); the format is this
+ * library's own.  dpf_load: device < 0 keeps the saved device ordinal; errors
+ * are reported through dpf_last_error(NULL). */
+int dpf_save(dpf_index *ix, const char *path);
+int dpf_load(const char *path, int32_t device, dpf_index **out);
+/* The configuration a handle was created (or loaded) with. */
+int dpf_get_config(const dpf_index *ix, dpf_config *out);
 
 /* RandomDrawTreeMap.allSubIndexObjectsNumberDistribution via
  * DensevectorRDFInit.getDtAndHtNumDistribution (Dense:515-530):

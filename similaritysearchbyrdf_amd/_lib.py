@@ -43,6 +43,7 @@ EXPORTS = (
     "dpf_set_sampling_index", "dpf_fit", "dpf_hash_batch", "dpf_query_batch", "dpf_free",
     "dpf_query_topk", "dpf_query_topk_device", "dpf_rerank", "dpf_merge_topk_device",
     "dpf_subindex_distribution", "dpf_get_stats", "dpf_last_rerank_profile", "dpf_set_profiling",
+    "dpf_save", "dpf_load", "dpf_get_config",
 )
 
 _lib = None
@@ -100,6 +101,12 @@ def lib():
     L.dpf_last_rerank_profile.argtypes = [vp, dp, i64p]
     L.dpf_set_profiling.restype = C.c_int
     L.dpf_set_profiling.argtypes = [vp, C.c_int32]
+    L.dpf_save.restype = C.c_int
+    L.dpf_save.argtypes = [vp, C.c_char_p]
+    L.dpf_load.restype = C.c_int
+    L.dpf_load.argtypes = [C.c_char_p, C.c_int32, C.POINTER(vp)]
+    L.dpf_get_config.restype = C.c_int
+    L.dpf_get_config.argtypes = [vp, C.POINTER(DpfConfig)]
     _lib = L
     return L
 
@@ -166,6 +173,25 @@ class DpfIndex:
     def _check(self, rc):
         if rc != 0:
             raise DpfError(rc, self.L_.dpf_last_error(self.h).decode())
+
+    def save(self, path):
+        """Writes the fitted index (configuration, hash family, hashes, resident rows) to one file."""
+        self._check(self.L_.dpf_save(self.h, os.fsencode(path)))
+
+    @classmethod
+    def load(cls, path, device=-1):
+        """A handle equal to the one `save` was called on; device < 0 keeps the saved ordinal."""
+        self = cls.__new__(cls)
+        self.L_ = lib()
+        self.h = C.c_void_p()
+        rc = self.L_.dpf_load(os.fsencode(path), device, C.byref(self.h))
+        if rc != 0:
+            raise DpfError(rc, self.L_.dpf_last_error(None).decode())
+        self.cfg = DpfConfig()
+        self._check(self.L_.dpf_get_config(self.h, C.byref(self.cfg)))
+        self.np_dtype = np.dtype({v: k for k, v in DTYPE.items()}[self.cfg.dtype])
+        self.dim, self.L, self.pb, self.top_k = self.cfg.dim, self.cfg.num_tables, self.cfg.partition_bits, self.cfg.top_k
+        return self
 
     def close(self):
         if getattr(self, "h", None) and self.h.value:

@@ -373,6 +373,39 @@ static int upload_snapshot(dpf_index *ix, ForestSnapshot &s)
 }
 
 
+// Second half of a fit, shared with dpf_load: the resident rows are in d_base and the hashes of all
+// `total` ids in h_hashes / h_parts; make the fp16 copy, build the forest and upload it.
+static int finish_fit(dpf_index *ix, int64_t total, int64_t new_rows)
+{
+    int rc;
+    const int d = ix->cfg.dim;
+    const size_t row_bytes = (size_t)ix->dpad * ix->elem;
+    if (ix->bucket_major && ix->ks16 > 0 && new_rows > 0) {
+        HIPCHECK(ix, ix->d_base16.ensure((size_t)new_rows * ix->ks16 * 32 * 2));
+        HIPCHECK(ix, ix->d_base16n.ensure((size_t)new_rows * 4));
+        HIPCHECK(ix, ix->d_base16e.ensure((size_t)new_rows * 4));
+        launch_rows_to_f16(ix->d_base.as<float>(), ix->dpad, d, new_rows, ix->d_base16.as<uint16_t>(), ix->ks16 * 32,
+                            ix->d_base16n.as<float>(), ix->d_base16e.as<float>(), nullptr);
+    }
+    HIPCHECK(ix, hipDeviceSynchronize());
+    ix->base_rows = new_rows;
+    ix->n = total;
+    ix->st.num_vectors = total;
+    ix->st.base_bytes = (int64_t)((size_t)new_rows * row_bytes);
+
+    ForestSnapshot snap;
+    int hw = (int)std::thread::hardware_concurrency();
+    const char *env = getenv("OMP_NUM_THREADS");
+    int threads = env ? atoi(env) : std::min(hw > 0 ? hw : 8, 16);
+    if (threads < 1) threads = 1;
+    if (build_forest(ix->geo, ix->h_hashes.data(), ix->h_parts.data(), total, threads, snap) != 0)
+        return fail(ix, DPF_ECAPACITY, "dpf_fit: snapshot exceeds 32-bit arena indexing");
+    if ((rc = upload_snapshot(ix, snap)) != DPF_OK) return rc;
+    ix->fitted = total > 0;
+    ix->last_valid = false;
+    return DPF_OK;
+}
+
 extern "C" int dpf_fit(dpf_index *ix, const void *X, int64_t n)
 {
     if (!ix) return DPF_EINVAL;
@@ -435,29 +468,139 @@ extern "C" int dpf_fit(dpf_index *ix, const void *X, int64_t n)
         HIPCHECK(ix, hipMemcpy(ix->h_hashes.data() + (size_t)g0 * L, ix->ws_hashes.p, (size_t)cnt * L * 4, hipMemcpyDeviceToHost));
         HIPCHECK(ix, hipMemcpy(ix->h_parts.data() + (size_t)g0 * L, ix->ws_parts.p, (size_t)cnt * L * 4, hipMemcpyDeviceToHost));
     }
-    if (ix->bucket_major && ix->ks16 > 0 && new_rows > 0) {
-        HIPCHECK(ix, ix->d_base16.ensure((size_t)new_rows * ix->ks16 * 32 * 2));
-        HIPCHECK(ix, ix->d_base16n.ensure((size_t)new_rows * 4));
-        HIPCHECK(ix, ix->d_base16e.ensure((size_t)new_rows * 4));
-        launch_rows_to_f16(ix->d_base.as<float>(), ix->dpad, d, new_rows, ix->d_base16.as<uint16_t>(), ix->ks16 * 32,
-                            ix->d_base16n.as<float>(), ix->d_base16e.as<float>(), nullptr);
-    }
-    HIPCHECK(ix, hipDeviceSynchronize());
-    ix->base_rows = new_rows;
-    ix->n = total;
-    ix->st.num_vectors = total;
-    ix->st.base_bytes = (int64_t)((size_t)new_rows * row_bytes);
+    return finish_fit(ix, total, new_rows);
+}
 
-    ForestSnapshot snap;
-    int hw = (int)std::thread::hardware_concurrency();
-    const char *env = getenv("OMP_NUM_THREADS");
-    int threads = env ? atoi(env) : std::min(hw > 0 ? hw : 8, 16);
-    if (threads < 1) threads = 1;
-    if (build_forest(ix->geo, ix->h_hashes.data(), ix->h_parts.data(), total, threads, snap) != 0)
-        return fail(ix, DPF_ECAPACITY, "dpf_fit: snapshot exceeds 32-bit arena indexing");
-    if ((rc = upload_snapshot(ix, snap)) != DPF_OK) return rc;
-    ix->fitted = total > 0;
-    ix->last_valid = false;
+// ---------------------------------------------------------------------------
+// dpf_save / dpf_load: one file holds what a fitted handle cannot recompute
+// without the caller's data: the configuration, the hash family and the
+// partitioner, the hashes of every id and the resident rows.  The forest
+// itself is rebuilt on load (it is a pure function of the hashes).
+// ---------------------------------------------------------------------------
+namespace {
+const char SNAP_MAGIC[8] = {'D', 'P', 'F', 'S', 'N', 'A', 'P', '1'};
+
+struct FileW {
+    FILE *f; bool ok = true;
+    void put(const void *p, size_t n) { if (ok && n && fwrite(p, 1, n, f) != n) ok = false; }
+    template <typename T> void val(const T &v) { put(&v, sizeof(T)); }
+    template <typename T> void vec(const std::vector<T> &v) { const uint64_t n = v.size(); val(n); put(v.data(), n * sizeof(T)); }
+};
+struct FileR {
+    FILE *f; bool ok = true;
+    void get(void *p, size_t n) { if (ok && n && fread(p, 1, n, f) != n) ok = false; }
+    template <typename T> void val(T &v) { get(&v, sizeof(T)); }
+    template <typename T> void vec(std::vector<T> &v, uint64_t most)
+    {
+        uint64_t n = 0; val(n);
+        if (!ok || n > most) { ok = false; return; }
+        v.resize((size_t)n); get(v.data(), (size_t)n * sizeof(T));
+    }
+};
+}  // namespace
+
+extern "C" int dpf_get_config(const dpf_index *ix, dpf_config *out)
+{
+    if (!ix || !out) return DPF_EINVAL;
+    *out = ix->cfg;
+    return DPF_OK;
+}
+
+extern "C" int dpf_save(dpf_index *ix, const char *path)
+{
+    if (!ix || !path) return DPF_EINVAL;
+    int rc = check_ready(ix, true);
+    if (rc != DPF_OK) return rc;
+    HIPCHECK(ix, hipSetDevice(ix->cfg.device));
+    FILE *f = fopen(path, "wb");
+    if (!f) return fail(ix, DPF_EINVAL, std::string("dpf_save: cannot open ") + path);
+    FileW w{f};
+    w.put(SNAP_MAGIC, 8);
+    w.val(ix->cfg);
+    w.put(ix->hp.sampling_index, sizeof(ix->hp.sampling_index));
+    w.val(ix->n); w.val(ix->base_rows); w.val(ix->maxnorm);
+    w.vec(ix->fns); w.vec(ix->chain_fn); w.vec(ix->b); w.vec(ix->w);
+    w.vec(ix->part_fns); w.vec(ix->part_b); w.vec(ix->part_w);
+    w.vec(ix->h_hashes); w.vec(ix->h_parts);
+    // resident rows, padding stripped
+    const size_t row_bytes = (size_t)ix->dpad * ix->elem, out_row = (size_t)ix->cfg.dim * ix->elem;
+    const int64_t batch = 1 << 16;
+    std::vector<char> pad((size_t)std::min<int64_t>(batch, std::max<int64_t>(ix->base_rows, 1)) * row_bytes), flat;
+    for (int64_t s0 = 0; s0 < ix->base_rows && w.ok; s0 += batch) {
+        const int64_t cnt = std::min(batch, ix->base_rows - s0);
+        hipError_t e = hipMemcpy(pad.data(), (const char *)ix->d_base.p + (size_t)s0 * row_bytes, (size_t)cnt * row_bytes, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { fclose(f); ix->err = std::string("dpf_save: ") + hipGetErrorString(e); return DPF_EHIP; }
+        flat.resize((size_t)cnt * out_row);
+        for (int64_t i = 0; i < cnt; i++) memcpy(flat.data() + (size_t)i * out_row, pad.data() + (size_t)i * row_bytes, out_row);
+        w.put(flat.data(), flat.size());
+    }
+    w.put(SNAP_MAGIC, 8);                                 // trailer: a truncated file does not load
+    const bool ok = w.ok && fclose(f) == 0;
+    if (!ok) return fail(ix, DPF_EINVAL, std::string("dpf_save: write failed on ") + path);
+    return DPF_OK;
+}
+
+extern "C" int dpf_load(const char *path, int32_t device, dpf_index **out)
+{
+    if (!path || !out) return DPF_EINVAL;
+    *out = nullptr;
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail(nullptr, DPF_EINVAL, std::string("dpf_load: cannot open ") + path);
+    FileR r{f};
+    char magic[8];
+    dpf_config cfg{};
+    int32_t si[32];
+    int64_t n = 0, base_rows = 0;
+    double maxnorm = 0;
+    r.get(magic, 8);
+    if (!r.ok || memcmp(magic, SNAP_MAGIC, 8) != 0) { fclose(f); return fail(nullptr, DPF_EINVAL, "dpf_load: not a snapshot file of this library version"); }
+    r.val(cfg); r.get(si, sizeof(si)); r.val(n); r.val(base_rows); r.val(maxnorm);
+    if (!r.ok || n < 0 || base_rows < 0 || base_rows > n) { fclose(f); return fail(nullptr, DPF_EINVAL, "dpf_load: damaged header"); }
+    if (device >= 0) cfg.device = device;
+    dpf_index *ix = nullptr;
+    int rc = dpf_create(&cfg, &ix);
+    if (rc != DPF_OK) { fclose(f); return rc; }
+    auto bail = [&](int code, const std::string &msg) { fclose(f); g_create_error = msg; dpf_destroy(ix); return code; };
+    const uint64_t big = (uint64_t)1 << 40;
+    std::vector<double> fns, b, part_fns, part_b;
+    std::vector<int32_t> w, chain_fn, part_w, hh, hp;
+    r.vec(fns, big); r.vec(chain_fn, big); r.vec(b, big); r.vec(w, big);
+    r.vec(part_fns, big); r.vec(part_b, big); r.vec(part_w, big);
+    r.vec(hh, big); r.vec(hp, big);
+    const size_t F = (size_t)cfg.num_functions, d = (size_t)cfg.dim, L = (size_t)cfg.num_tables, m = (size_t)cfg.chain_length,
+                 pb = (size_t)cfg.partition_bits;
+    if (!r.ok || fns.size() != F * d || chain_fn.size() != L * m || hh.size() != (size_t)n * L || hp.size() != (size_t)n * L ||
+        (cfg.family == DPF_FAMILY_PSTABLE && (b.size() != F || w.size() != F)) || (pb > 0 && part_fns.size() != L * pb * 32))
+        return bail(DPF_EINVAL, "dpf_load: damaged or truncated file");
+    if ((rc = dpf_set_hash_family(ix, fns.data(), b.empty() ? nullptr : b.data(), w.empty() ? nullptr : w.data(), chain_fn.data())) != DPF_OK ||
+        (pb > 0 && (rc = dpf_set_partitioner(ix, part_fns.data(), part_b.empty() ? nullptr : part_b.data(),
+                                             part_w.empty() ? nullptr : part_w.data())) != DPF_OK) ||
+        (rc = dpf_set_sampling_index(ix, si)) != DPF_OK)
+        return bail(rc, std::string("dpf_load: ") + ix->err);
+    // resident rows
+    const size_t row_bytes = (size_t)ix->dpad * ix->elem, in_row = d * ix->elem;
+    hipError_t e = ix->d_base.ensure(std::max<size_t>((size_t)base_rows * row_bytes, 16));
+    const int64_t batch = 1 << 16;
+    std::vector<char> flat((size_t)std::min<int64_t>(batch, std::max<int64_t>(base_rows, 1)) * in_row);
+    if (e == hipSuccess) e = ix->ws_stage.ensure(flat.size());
+    for (int64_t s0 = 0; s0 < base_rows && e == hipSuccess && r.ok; s0 += batch) {
+        const int64_t cnt = std::min(batch, base_rows - s0);
+        r.get(flat.data(), (size_t)cnt * in_row);
+        if (!r.ok) break;
+        e = hipMemcpy(ix->ws_stage.p, flat.data(), (size_t)cnt * in_row, hipMemcpyHostToDevice);
+        if (e == hipSuccess)
+            launch_copy_rows(cfg.dtype, ix->ws_stage.p, cnt, (int)d, (char *)ix->d_base.p + (size_t)s0 * row_bytes, ix->dpad, nullptr);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+    }
+    r.get(magic, 8);
+    if (e != hipSuccess) return bail(DPF_EHIP, std::string("dpf_load: ") + hipGetErrorString(e));
+    if (!r.ok || memcmp(magic, SNAP_MAGIC, 8) != 0) return bail(DPF_EINVAL, "dpf_load: damaged or truncated file");
+    fclose(f);
+    ix->h_hashes.swap(hh);
+    ix->h_parts.swap(hp);
+    ix->maxnorm = maxnorm;
+    if ((rc = finish_fit(ix, n, base_rows)) != DPF_OK) { g_create_error = "dpf_load: " + ix->err; dpf_destroy(ix); return rc; }
+    *out = ix;
     return DPF_OK;
 }
 

@@ -456,3 +456,37 @@ def test_table_shards_and_merge(metric):
     assert_topk_equal(o_ids.cpu().numpy(), o_sc.cpu().numpy(), want[0], want[1])
     with pytest.raises(Exception):
         DpfIndex(params, metric=metric, table_begin=4, table_end=9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,family", [(np.float32, "angle"), (np.float64, "pStable")])
+def test_save_and_load_round_trip(tmp_path, dtype, family):
+    # a loaded handle answers exactly as the saved one (sets, top-k, stats), accepts further fits
+    # like the original, and damaged files are refused
+    kw = dict(table_num=2, permutation_num=2) if family == "angle" else dict(table_num=3, permutation_num=1)
+    params, X, Q, pick = make_problem(n=5000, nq=40, bucket_overflow=40, family=family, **kw)
+    a = DpfIndex(params, metric="l2", dtype=dtype)
+    a.fit(X[:3000])
+    path = str(tmp_path / "index.dpf")
+    a.save(path)
+    b = DpfIndex.load(path)
+    assert (b.dim, b.L, b.pb) == (a.dim, a.L, a.pb) and b.np_dtype == a.np_dtype
+    for ix in (a, b):
+        ix.fit(X[3000:])                                   # incremental fit on both
+    ao, ai = a.query_batch(pick, Q, steps=1)
+    bo, bi = b.query_batch(pick, Q, steps=1)
+    assert np.array_equal(ao, bo) and np.array_equal(ai, bi)
+    at, as_ = a.query_topk(pick, Q, steps=1, k=10)
+    bt, bs = b.query_topk(pick, Q, steps=1, k=10)
+    assert np.array_equal(at, bt) and np.array_equal(as_, bs, equal_nan=True)
+    sa, sb = a.stats(), b.stats()
+    for key in ("num_vectors", "num_dnodes", "num_leaves", "max_leaf", "misflag_events"):
+        assert sa[key] == sb[key]
+    blob = open(path, "rb").read()
+    bad = str(tmp_path / "bad.dpf")
+    open(bad, "wb").write(blob[:len(blob) // 2])
+    with pytest.raises(Exception):
+        DpfIndex.load(bad)
+    open(bad, "wb").write(b"garbage!" + blob[8:])
+    with pytest.raises(Exception):
+        DpfIndex.load(bad)
