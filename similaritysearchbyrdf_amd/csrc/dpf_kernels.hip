@@ -1311,7 +1311,6 @@ __global__ __launch_bounds__(256, ls16_waves(KS, RB)) void k_leafscan_f16(LeafSc
     const uint32_t jq = 4u * (uint32_t)(i16 & 3) + (uint32_t)(i16 >> 2);
     constexpr int STRIDE = KS * 32;                       // fp16 elements per padded row
     const unsigned long long lt = (1ull << lane) - 1ull;
-    const unsigned long long gmask = 0xffffull << (16 * g);
     // fp32 accumulation of the products and of the norms plus the roundings of the threshold
     // arithmetic below, per unit of |q~|^2 + |x~|^2
     const float c32 = (3.0f * (float)(STRIDE + 8) + 24.0f) * 5.9604645e-8f;
@@ -1401,10 +1400,11 @@ __global__ __launch_bounds__(256, ls16_waves(KS, RB)) void k_leafscan_f16(LeafSc
             {
                 float G = HUGE_VALF, G2 = HUGE_VALF, dslack = 0.f;
                 if (qcur >= 0) {
-                    const float qr = sqrtf(m_qn) * 1.00001f;         // upper bound of |q~|
+                    // v_sqrt_f32 (1 ulp) with the margin folded into the factors below
+                    const float qr = __builtin_amdgcn_sqrtf(m_qn) * 1.00001f;   // upper bound of |q~|
                     if (METRIC == 1) {
                         if (m_tau >= 0.f) {
-                            const float st = sqrtf(m_tau);
+                            const float st = __builtin_amdgcn_sqrtf(m_tau) * 1.000001f;
                             const float hi = st + m_qe + cxm;
                             G = fmaxf(0.5f * (m_qn * (1.0f - c32) - hi * hi * 1.000001f), -3.0e38f);
                             const float w = 0.985f * st - m_qe - cxm;
@@ -1444,7 +1444,7 @@ __global__ __launch_bounds__(256, ls16_waves(KS, RB)) void k_leafscan_f16(LeafSc
                 const float4 sc = s_slot[wave][slot];
                 float d[RB];
                 bool pass[RB];
-                int tight = 0;
+                int tight = 0;                            // this lane's rows inside the trigger level
                 unsigned long long many = 0;
 #pragma unroll
                 for (int rb = 0; rb < RB; rb++) {
@@ -1452,7 +1452,12 @@ __global__ __launch_bounds__(256, ls16_waves(KS, RB)) void k_leafscan_f16(LeafSc
                     pass[rb] = d[rb] >= sc.x;
                     if (rb * 16u >= rows && rb > 0) { pass[rb] = false; continue; }
                     many |= __ballot(pass[rb]);
-                    if (METRIC == 1) tight += __popcll(__ballot(d[rb] >= sc.y) & gmask);
+                    if (METRIC == 1) tight += d[rb] >= sc.y ? 1 : 0;
+                }
+                if (METRIC == 1 && __ballot(tight != 0)) {
+                    // rows of the 16-lane group (one query) inside the trigger level
+#pragma unroll
+                    for (int o = 1; o < 16; o <<= 1) tight += __shfl_xor(tight, o);
                 }
                 if (many) {
                     const int32_t qq = __float_as_int(sc.z), qidq = __float_as_int(sc.w);

@@ -1,0 +1,12 @@
+#!/bin/bash
+# instruction mix and wave-cycle breakdown of the kernels of one c3 batch loop (run from the repository root on the GPU box)
+R=$PWD
+cd /tmp && export TMPDIR=/tmp
+i=0
+for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES" \
+           "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM_RD" \
+           "SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_IFETCH SQ_LDS_BANK_CONFLICT SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_INSTS_BRANCH SQ_CYCLES"; do
+  i=$((i+1))
+  timeout -s KILL 120 rocprofv3 --pmc $set -d $R/gpurun_out/pmc_i$i -o p --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-recall > $R/gpurun_out/pmc_i$i.log 2>&1 || { tail -3 $R/gpurun_out/pmc_i$i.log; exit 1; }
+done
+echo done
