@@ -1283,6 +1283,213 @@ void launch_tile_maxnorm(uint4 *tiles, int64_t ntiles, const int32_t *ids, const
     if (ntiles > 0) hipLaunchKernelGGL(k_tile_maxnorm, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, stream, tiles, ntiles, ids, norms, errs, row_begin, row_end);
 }
 
+// The queries of one unit against the tile a wave holds in registers, 16 at a time: thresholds,
+// products on the matrix cores, tests, forwarding.  Shared by the two scan kernels, which differ
+// in how the tile reaches the registers.  s_* are this wave's LDS areas: forwarded (query, id,
+// bound) triples parked until 64 are there; per query slot {G, G2, bits of query index, bits of
+// query id} and {|q~|^2, l2: |q - q~|, dot: the slot's slack}.
+template <int KS, int METRIC, int RB>
+__device__ __forceinline__ void leafscan_chunks(const LeafScanParams &p, const uint16_t *__restrict__ Q16, const f16x8 (&xb)[RB][KS],
+                                                const float (&xn)[RB], const int32_t (&idj)[RB], uint32_t rows, uint32_t nq,
+                                                uint32_t lq0, float xrm, float cxm, int32_t qsc, int32_t qsn, int32_t *s_fq,
+                                                int32_t *s_fid, float *s_fv, float4 *s_slot, float2 *s_slot2, int &nbuf)
+{
+    const int lane = threadIdx.x & 63;
+    const int i16 = lane & 15, g = lane >> 4;
+    const uint32_t jq = 4u * (uint32_t)(i16 & 3) + (uint32_t)(i16 >> 2);   // chunk position of this lane's MFMA row
+    constexpr int STRIDE = KS * 32;                       // fp16 elements per padded row
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    // fp32 accumulation of the products and of the norms plus the roundings of the threshold
+    // arithmetic below, per unit of |q~|^2 + |x~|^2
+    const float c32 = (3.0f * (float)(STRIDE + 8) + 24.0f) * 5.9604645e-8f;
+    auto flush = [&](int n) {
+        if (lane < n) {
+            const int32_t fq = s_fq[lane];
+            const int at = atomicAdd(&p.emit_cnt[fq], 1);
+            if (at < p.emit_cap) {
+                p.emit[(size_t)fq * p.emit_cap + at] = s_fid[lane];
+                p.emit_v[(size_t)fq * p.emit_cap + at] = s_fv[lane];
+            }
+        }
+    };
+    float J[RB];                                          // the row's share of the threshold
+#pragma unroll
+    for (int rb = 0; rb < RB; rb++)                       // an absent row never reaches any threshold
+        J[rb] = idj[rb] >= 0 ? (METRIC == 1 ? 0.5f * xn[rb] * (1.0f - c32) : 0.f) : HUGE_VALF;
+
+    for (uint32_t c = 0; c < nq; c += 16u) {
+        f16x8 qa[KS];
+        const size_t qat = (size_t)(qsc >= 0 ? qsc : 0);
+        {
+            const uint16_t *qrow = Q16 + qat * STRIDE + 8 * g;
+#pragma unroll
+            for (int t = 0; t < KS; t++) qa[t] = *(const f16x8 *)(qrow + 32 * t);
+        }
+        const float m_tau = dec_f32(__hip_atomic_load(&p.tau[qat], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        const float m_qn = p.q16_norm[qat], m_qe = p.q16_err[qat];
+        const int32_t m_qid = p.qids ? p.qids[qat] : -1;
+        const int32_t qcur = qsc;
+        // query indices two chunks ahead
+        qsc = qsn;
+        qsn = c + 32u + jq < nq ? p.leaf_queries[lq0 + c + 32u + jq] : -1;
+
+        // Per-slot thresholds on d = q~.x~ - J(row); lane i16 of every 16-lane group holds query slot i16.
+        //   l2:  | |q~ - x~| - |q - x| | <= |q - q~| + |x - x~| =: eta, so forward when |q~ - x~|^2 could be
+        //        <= (sqrt(tau) + eta)^2 with the tile's largest |x - x~|:
+        //        q~.x~ - |x~|^2/2 >= (|q~|^2 - (sqrt(tau) + eta)^2) / 2 =: G, rounding taken on the safe side
+        //   dot: |q.x - q~.x~| <= |q - q~||x~| + |q||x - x~|, so forward when q~.x~ + that slack >= tau
+        // G2 is the level at which a row is roughly inside 0.985 sqrt(tau); it only triggers the
+        // exact selection below, so it needs no rigour.
+        {
+            float G = HUGE_VALF, G2 = HUGE_VALF, dslack = 0.f;
+            if (qcur >= 0) {
+                // v_sqrt_f32 (1 ulp) with the margin folded into the factors below
+                const float qr = __builtin_amdgcn_sqrtf(m_qn) * 1.00001f;   // upper bound of |q~|
+                if (METRIC == 1) {
+                    if (m_tau >= 0.f) {
+                        const float st = __builtin_amdgcn_sqrtf(m_tau) * 1.000001f;
+                        const float hi = st + m_qe + cxm;
+                        G = fmaxf(0.5f * (m_qn * (1.0f - c32) - hi * hi * 1.000001f), -3.0e38f);
+                        const float w = 0.985f * st - m_qe - cxm;
+                        if (w > 0.f) G2 = fmaxf(0.5f * (m_qn * (1.0f + c32) - w * w) + c32 * xrm * xrm, -3.0e38f);
+                    }
+                } else {
+                    dslack = (m_qe * xrm + (qr + m_qe) * cxm + c32 * qr * xrm) * 1.00001f + 1e-30f;
+                    G = fmaxf(m_tau - dslack, -3.0e38f);
+                }
+            }
+            if (g == 0) {
+                s_slot[i16] = make_float4(G, G2, __int_as_float(qcur), __int_as_float(m_qid));
+                s_slot2[i16] = make_float2(m_qn, METRIC == 1 ? m_qe : dslack);
+            }
+        }
+        f32x4 acc[RB];
+#pragma unroll
+        for (int rb = 0; rb < RB; rb++) {
+            acc[rb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (rb * 16u >= rows && rb > 0) continue;
+#pragma unroll
+            for (int t = 0; t < KS; t++) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qa[t], xb[rb][t], acc[rb], 0, 0, 0);
+        }
+        // lane l holds q~(MFMA row 4g + r) . x~(rb*16 + i16) in acc[rb][r]
+        const uint32_t nslot = min(16u, nq - c);       // queries in this chunk
+        if (p.debug) {                                // ablation runs: loads and products only
+            float t = 0.f;
+#pragma unroll
+            for (int rb = 0; rb < RB; rb++) t += acc[rb][rb];
+            if (t == 12345.678f) nbuf = 1;
+            continue;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            if (4u * r >= nslot) break;
+            const int slot = 4 * g + r;
+            const float4 sc = s_slot[slot];
+            float d[RB];
+            bool pass[RB];
+            int tight = 0;                            // this lane's rows inside the trigger level
+            unsigned long long many = 0;
+#pragma unroll
+            for (int rb = 0; rb < RB; rb++) {
+                d[rb] = acc[rb][r] - J[rb];
+                pass[rb] = d[rb] >= sc.x;
+                if (rb * 16u >= rows && rb > 0) { pass[rb] = false; continue; }
+                many |= __ballot(pass[rb]);
+                if (METRIC == 1) tight += d[rb] >= sc.y ? 1 : 0;
+            }
+            if (METRIC == 1 && __ballot(tight != 0)) {
+                // rows of the 16-lane group (one query) inside the trigger level
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) tight += __shfl_xor(tight, o);
+            }
+            if (many) {
+                const int32_t qq = __float_as_int(sc.z), qidq = __float_as_int(sc.w);
+                const float2 s2 = s_slot2[slot];
+#pragma unroll
+                for (int rb = 0; rb < RB; rb++) {
+                    const bool fwd = pass[rb] && !self_excluded(idj[rb], qidq, p.exclude_self);
+                    const unsigned long long m = __ballot(fwd);
+                    if (m) {
+                        if (fwd) {
+                            const int at = nbuf + __popcll(m & lt);
+                            s_fq[at] = qq;
+                            s_fid[at] = idj[rb];
+                            // l2: sqrt(exact distance) <= sqrt(s_hi) + |x - x~|max + |q - q~|, the query's share is
+                            // added by the reader; dot: exact product >= q~.x~ - slack
+                            if (METRIC == 1) {
+                                const float s_hi = fmaf(-2.0f, acc[rb][r], (s2.x + xn[rb]) * (1.0f + c32));
+                                s_fv[at] = sqrtf(fmaxf(s_hi, 0.f)) * 1.000001f + cxm;
+                            } else {
+                                s_fv[at] = acc[rb][r] - s2.y * 1.000001f;
+                            }
+                        }
+                        nbuf += __popcll(m);
+                        if (nbuf >= 64) {
+                            flush(64);
+                            const int rest = nbuf - 64;
+                            int32_t tq2 = 0, ti2 = 0;
+                            float tv2 = 0.f;
+                            if (lane < rest) { tq2 = s_fq[64 + lane]; ti2 = s_fid[64 + lane]; tv2 = s_fv[64 + lane]; }
+                            if (lane < rest) { s_fq[lane] = tq2; s_fid[lane] = ti2; s_fv[lane] = tv2; }
+                            nbuf = rest;
+                        }
+                    }
+                }
+            }
+            if (METRIC == 1 && tight >= p.k) {
+                // Roughly k or more rows of this tile sit inside 0.985 sqrt(tau).  With
+                //   v = sqrt(s_hi) + |x - x~|max >= sqrt(exact distance) - |q - q~|
+                // (s_hi = |q~ - x~|^2 rounded up), the k-th smallest v among the RB*16 rows this 16-lane
+                // group holds for the query bounds the query's k-th best distance from above.
+                const int32_t qq = __float_as_int(sc.z), qidq = __float_as_int(sc.w);
+                const float2 s2 = s_slot2[slot];
+                float v[RB];
+#pragma unroll
+                for (int rb = 0; rb < RB; rb++) {
+                    const bool ok = idj[rb] >= 0 && !self_excluded(idj[rb], qidq, p.exclude_self);
+                    const float s_hi = fmaf(-2.0f, acc[rb][r], (s2.x + xn[rb]) * (1.0f + c32));
+                    v[rb] = ok ? sqrtf(fmaxf(s_hi, 0.f)) * 1.000001f + cxm : HUGE_VALF;
+                }
+                int rank[RB];
+#pragma unroll
+                for (int mb = 0; mb < RB; mb++) rank[mb] = 0;
+                for (int j = 0; j < 16; j++) {
+                    const int src = 16 * g + j;
+#pragma unroll
+                    for (int ob = 0; ob < RB; ob++) {
+                        const float o = __shfl(v[ob], src);
+#pragma unroll
+                        for (int mb = 0; mb < RB; mb++)
+                            rank[mb] += (o < v[mb] || (o == v[mb] && (j < i16 || (j == i16 && ob < mb)))) ? 1 : 0;
+                    }
+                }
+#pragma unroll
+                for (int mb = 0; mb < RB; mb++) {
+                    if (rank[mb] == p.k - 1 && v[mb] < HUGE_VALF) {
+                        const float b = (v[mb] + s2.y) * 1.000001f;
+                        atomicMin(&p.tau[qq], enc_f32(b * b * 1.000001f));
+                    }
+                }
+            }
+        }
+    }
+}
+
+// what is still parked when a wave runs out of units
+__device__ __forceinline__ void leafscan_flush_rest(const LeafScanParams &p, const int32_t *s_fq, const int32_t *s_fid, const float *s_fv,
+                                                    int nbuf)
+{
+    const int lane = threadIdx.x & 63;
+    if (lane < nbuf) {
+        const int32_t fq = s_fq[lane];
+        const int at = atomicAdd(&p.emit_cnt[fq], 1);
+        if (at < p.emit_cap) {
+            p.emit[(size_t)fq * p.emit_cap + at] = s_fid[lane];
+            p.emit_v[(size_t)fq * p.emit_cap + at] = s_fv[lane];
+        }
+    }
+}
+
 // Persistent waves; wave w takes units w, w + W, w + 2W, ...  A unit needs two dependent levels
 // of loads (descriptor -> ids / query indices -> rows / query rows): descriptors run two units
 // ahead and ids one, query indices one 16-query chunk ahead, so a wave waits once per unit (rows +
@@ -1296,9 +1503,9 @@ __global__ __launch_bounds__(256, ls16_waves(KS, RB)) void k_leafscan_f16(LeafSc
                                                                           const uint16_t *__restrict__ B16)
 {
     __shared__ int32_t s_fq[4][128], s_fid[4][128];
-    __shared__ float s_fv[4][128];                        // pessimistic bound of the forwarded row's exact score
-    __shared__ float4 s_slot[4][16];                      // per query slot: {G, G2, bits of query index, bits of query id}
-    __shared__ float2 s_slot2[4][16];                     // {|q~|^2, l2: |q - q~|, dot: the slot's slack}
+    __shared__ float s_fv[4][128];
+    __shared__ float4 s_slot[4][16];
+    __shared__ float2 s_slot2[4][16];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t W = gridDim.x * 4u, nunits = (uint32_t)p.unit_end;
@@ -1310,23 +1517,9 @@ __global__ __launch_bounds__(256, ls16_waves(KS, RB)) void k_leafscan_f16(LeafSc
     // ceil(n/4) registers tested; jq = the chunk position this lane's row holds.
     const uint32_t jq = 4u * (uint32_t)(i16 & 3) + (uint32_t)(i16 >> 2);
     constexpr int STRIDE = KS * 32;                       // fp16 elements per padded row
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    // fp32 accumulation of the products and of the norms plus the roundings of the threshold
-    // arithmetic below, per unit of |q~|^2 + |x~|^2
-    const float c32 = (3.0f * (float)(STRIDE + 8) + 24.0f) * 5.9604645e-8f;
     const int32_t row_lo = (int32_t)p.row_begin, row_hi = (int32_t)p.row_end;
 
     int nbuf = 0;
-    auto flush = [&](int n) {
-        if (lane < n) {
-            const int32_t fq = s_fq[wave][lane];
-            const int at = atomicAdd(&p.emit_cnt[fq], 1);
-            if (at < p.emit_cap) {
-                p.emit[(size_t)fq * p.emit_cap + at] = s_fid[wave][lane];
-                p.emit_v[(size_t)fq * p.emit_cap + at] = s_fv[wave][lane];
-            }
-        }
-    };
     auto desc = [&](uint32_t uu) { return uu < nunits ? p.units[uu] : make_uint4(0u, 0u, 0u, 0u); };
     auto small = [&](const uint4 &U, int32_t (&id)[RB], int32_t &qs, int32_t &qsn) {
         const uint32_t rows = U.y & 0xffu, nq = U.y >> 8;
@@ -1348,7 +1541,7 @@ __global__ __launch_bounds__(256, ls16_waves(KS, RB)) void k_leafscan_f16(LeafSc
     for (; u < nunits; u += W) {
         // this unit's rows
         f16x8 xb[RB][KS];
-        float J[RB], xn[RB];                              // the row's share of the threshold; |x~|^2
+        float xn[RB];                                     // |x~|^2
         const uint32_t rows = U0.y & 0xffu;               // 16-row blocks past the tile's end are skipped throughout
 #pragma unroll
         for (int rb = 0; rb < RB; rb++) {
@@ -1366,172 +1559,14 @@ __global__ __launch_bounds__(256, ls16_waves(KS, RB)) void k_leafscan_f16(LeafSc
         const float xrm = __uint_as_float(U0.w & 0xffff0000u);    // upper bound of the largest |x~| of the tile
         const float cxm = __uint_as_float(U0.w << 16);            // upper bound of the largest |x - x~|
         // the next unit's ids and first query indices, the descriptor after it
-        int32_t qsc = qs0, qsn = qs0n;
+        const int32_t qsc = qs0, qsn = qs0n;
         U0 = U1;
         U1 = desc(u + 2u * W);
         small(U0, id0, qs0, qs0n);
-#pragma unroll
-        for (int rb = 0; rb < RB; rb++)                   // an absent row never reaches any threshold
-            J[rb] = idj[rb] >= 0 ? (METRIC == 1 ? 0.5f * xn[rb] * (1.0f - c32) : 0.f) : HUGE_VALF;
-
-        for (uint32_t c = 0; c < nq; c += 16u) {
-            f16x8 qa[KS];
-            const size_t qat = (size_t)(qsc >= 0 ? qsc : 0);
-            {
-                const uint16_t *qrow = Q16 + qat * STRIDE + 8 * g;
-#pragma unroll
-                for (int t = 0; t < KS; t++) qa[t] = *(const f16x8 *)(qrow + 32 * t);
-            }
-            const float m_tau = dec_f32(__hip_atomic_load(&p.tau[qat], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            const float m_qn = p.q16_norm[qat], m_qe = p.q16_err[qat];
-            const int32_t m_qid = p.qids ? p.qids[qat] : -1;
-            const int32_t qcur = qsc;
-            // query indices two chunks ahead
-            qsc = qsn;
-            qsn = c + 32u + jq < nq ? p.leaf_queries[lq0 + c + 32u + jq] : -1;
-
-            // Per-slot thresholds on d = q~.x~ - J(row); lane i16 of every 16-lane group holds query slot i16.
-            //   l2:  | |q~ - x~| - |q - x| | <= |q - q~| + |x - x~| =: eta, so forward when |q~ - x~|^2 could be
-            //        <= (sqrt(tau) + eta)^2 with the tile's largest |x - x~|:
-            //        q~.x~ - |x~|^2/2 >= (|q~|^2 - (sqrt(tau) + eta)^2) / 2 =: G, rounding taken on the safe side
-            //   dot: |q.x - q~.x~| <= |q - q~||x~| + |q||x - x~|, so forward when q~.x~ + that slack >= tau
-            // G2 is the level at which a row is roughly inside 0.985 sqrt(tau); it only triggers the
-            // exact selection below, so it needs no rigour.
-            {
-                float G = HUGE_VALF, G2 = HUGE_VALF, dslack = 0.f;
-                if (qcur >= 0) {
-                    // v_sqrt_f32 (1 ulp) with the margin folded into the factors below
-                    const float qr = __builtin_amdgcn_sqrtf(m_qn) * 1.00001f;   // upper bound of |q~|
-                    if (METRIC == 1) {
-                        if (m_tau >= 0.f) {
-                            const float st = __builtin_amdgcn_sqrtf(m_tau) * 1.000001f;
-                            const float hi = st + m_qe + cxm;
-                            G = fmaxf(0.5f * (m_qn * (1.0f - c32) - hi * hi * 1.000001f), -3.0e38f);
-                            const float w = 0.985f * st - m_qe - cxm;
-                            if (w > 0.f) G2 = fmaxf(0.5f * (m_qn * (1.0f + c32) - w * w) + c32 * xrm * xrm, -3.0e38f);
-                        }
-                    } else {
-                        dslack = (m_qe * xrm + (qr + m_qe) * cxm + c32 * qr * xrm) * 1.00001f + 1e-30f;
-                        G = fmaxf(m_tau - dslack, -3.0e38f);
-                    }
-                }
-                if (g == 0) {
-                    s_slot[wave][i16] = make_float4(G, G2, __int_as_float(qcur), __int_as_float(m_qid));
-                    s_slot2[wave][i16] = make_float2(m_qn, METRIC == 1 ? m_qe : dslack);
-                }
-            }
-            f32x4 acc[RB];
-#pragma unroll
-            for (int rb = 0; rb < RB; rb++) {
-                acc[rb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (rb * 16u >= rows && rb > 0) continue;
-#pragma unroll
-                for (int t = 0; t < KS; t++) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qa[t], xb[rb][t], acc[rb], 0, 0, 0);
-            }
-            // lane l holds q~(MFMA row 4g + r) . x~(rb*16 + i16) in acc[rb][r]
-            const uint32_t nslot = min(16u, nq - c);       // queries in this chunk
-            if (p.debug) {                                // ablation runs: loads and products only
-                float t = 0.f;
-#pragma unroll
-                for (int rb = 0; rb < RB; rb++) t += acc[rb][rb];
-                if (t == 12345.678f) nbuf = 1;
-                continue;
-            }
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                if (4u * r >= nslot) break;
-                const int slot = 4 * g + r;
-                const float4 sc = s_slot[wave][slot];
-                float d[RB];
-                bool pass[RB];
-                int tight = 0;                            // this lane's rows inside the trigger level
-                unsigned long long many = 0;
-#pragma unroll
-                for (int rb = 0; rb < RB; rb++) {
-                    d[rb] = acc[rb][r] - J[rb];
-                    pass[rb] = d[rb] >= sc.x;
-                    if (rb * 16u >= rows && rb > 0) { pass[rb] = false; continue; }
-                    many |= __ballot(pass[rb]);
-                    if (METRIC == 1) tight += d[rb] >= sc.y ? 1 : 0;
-                }
-                if (METRIC == 1 && __ballot(tight != 0)) {
-                    // rows of the 16-lane group (one query) inside the trigger level
-#pragma unroll
-                    for (int o = 1; o < 16; o <<= 1) tight += __shfl_xor(tight, o);
-                }
-                if (many) {
-                    const int32_t qq = __float_as_int(sc.z), qidq = __float_as_int(sc.w);
-                    const float2 s2 = s_slot2[wave][slot];
-#pragma unroll
-                    for (int rb = 0; rb < RB; rb++) {
-                        const bool fwd = pass[rb] && !self_excluded(idj[rb], qidq, p.exclude_self);
-                        const unsigned long long m = __ballot(fwd);
-                        if (m) {
-                            if (fwd) {
-                                const int at = nbuf + __popcll(m & lt);
-                                s_fq[wave][at] = qq;
-                                s_fid[wave][at] = idj[rb];
-                                // l2: sqrt(exact distance) <= sqrt(s_hi) + |x - x~|max + |q - q~|, the query's share is
-                                // added by the reader; dot: exact product >= q~.x~ - slack
-                                if (METRIC == 1) {
-                                    const float s_hi = fmaf(-2.0f, acc[rb][r], (s2.x + xn[rb]) * (1.0f + c32));
-                                    s_fv[wave][at] = sqrtf(fmaxf(s_hi, 0.f)) * 1.000001f + cxm;
-                                } else {
-                                    s_fv[wave][at] = acc[rb][r] - s2.y * 1.000001f;
-                                }
-                            }
-                            nbuf += __popcll(m);
-                            if (nbuf >= 64) {
-                                flush(64);
-                                const int rest = nbuf - 64;
-                                int32_t tq2 = 0, ti2 = 0;
-                                float tv2 = 0.f;
-                                if (lane < rest) { tq2 = s_fq[wave][64 + lane]; ti2 = s_fid[wave][64 + lane]; tv2 = s_fv[wave][64 + lane]; }
-                                if (lane < rest) { s_fq[wave][lane] = tq2; s_fid[wave][lane] = ti2; s_fv[wave][lane] = tv2; }
-                                nbuf = rest;
-                            }
-                        }
-                    }
-                }
-                if (METRIC == 1 && tight >= p.k) {
-                    // Roughly k or more rows of this tile sit inside 0.985 sqrt(tau).  With
-                    //   v = sqrt(s_hi) + |x - x~|max >= sqrt(exact distance) - |q - q~|
-                    // (s_hi = |q~ - x~|^2 rounded up), the k-th smallest v among the RB*16 rows this 16-lane
-                    // group holds for the query bounds the query's k-th best distance from above.
-                    const int32_t qq = __float_as_int(sc.z), qidq = __float_as_int(sc.w);
-                    const float2 s2 = s_slot2[wave][slot];
-                    float v[RB];
-#pragma unroll
-                    for (int rb = 0; rb < RB; rb++) {
-                        const bool ok = idj[rb] >= 0 && !self_excluded(idj[rb], qidq, p.exclude_self);
-                        const float s_hi = fmaf(-2.0f, acc[rb][r], (s2.x + xn[rb]) * (1.0f + c32));
-                        v[rb] = ok ? sqrtf(fmaxf(s_hi, 0.f)) * 1.000001f + cxm : HUGE_VALF;
-                    }
-                    int rank[RB];
-#pragma unroll
-                    for (int mb = 0; mb < RB; mb++) rank[mb] = 0;
-                    for (int j = 0; j < 16; j++) {
-                        const int src = 16 * g + j;
-#pragma unroll
-                        for (int ob = 0; ob < RB; ob++) {
-                            const float o = __shfl(v[ob], src);
-#pragma unroll
-                            for (int mb = 0; mb < RB; mb++)
-                                rank[mb] += (o < v[mb] || (o == v[mb] && (j < i16 || (j == i16 && ob < mb)))) ? 1 : 0;
-                        }
-                    }
-#pragma unroll
-                    for (int mb = 0; mb < RB; mb++) {
-                        if (rank[mb] == p.k - 1 && v[mb] < HUGE_VALF) {
-                            const float b = (v[mb] + s2.y) * 1.000001f;
-                            atomicMin(&p.tau[qq], enc_f32(b * b * 1.000001f));
-                        }
-                    }
-                }
-            }
-        }
+        leafscan_chunks<KS, METRIC, RB>(p, Q16, xb, xn, idj, rows, nq, lq0, xrm, cxm, qsc, qsn, s_fq[wave], s_fid[wave], s_fv[wave],
+                                        s_slot[wave], s_slot2[wave], nbuf);
     }
-    flush(nbuf);
+    leafscan_flush_rest(p, s_fq[wave], s_fid[wave], s_fv[wave], nbuf);
 }
 
 template <int METRIC, int RB>
