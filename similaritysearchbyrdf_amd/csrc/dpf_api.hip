@@ -60,6 +60,7 @@ struct dpf_index {
     int64_t base_rows = 0;                   // resident rows: ids row_begin .. row_begin+base_rows-1
 
     DevBuf d_roots, d_dnodes, d_leaf_off, d_ids;
+    DevBuf ws_emit_ucnt;                     // distinct ids per forward list
     DevBuf ws_emit_v, ws_leaf_units, ws_unit_off, ws_q_leaves, ws_q_leaf_cnt;
     DevBuf d_leaf_tile0, ws_units;           // first tile of each bucket; work units of the batch
     int num_cus = 256;
@@ -211,7 +212,7 @@ extern "C" void dpf_destroy(dpf_index *ix)
     if (ix->pinned) (void)hipHostFree(ix->pinned);
     for (int i = 0; i < 6; i++) if (ix->ev[i]) (void)hipEventDestroy(ix->ev[i]);
     for (int i = 0; i < 4; i++) if (ix->ev_scan[i]) (void)hipEventDestroy(ix->ev_scan[i]);
-    DevBuf *more[] = {&ix->ws_emit_v, &ix->ws_leaf_units, &ix->ws_unit_off, &ix->ws_q_leaves, &ix->ws_q_leaf_cnt, &ix->d_leaf_tile0, &ix->ws_units, &ix->d_tiles, &ix->d_tile_leaf, &ix->d_tile_row0, &ix->ws_lq_cnt, &ix->ws_lq_off, &ix->ws_lq_cursor, &ix->ws_leaf_queries,
+    DevBuf *more[] = {&ix->ws_emit_ucnt, &ix->ws_emit_v, &ix->ws_leaf_units, &ix->ws_unit_off, &ix->ws_q_leaves, &ix->ws_q_leaf_cnt, &ix->d_leaf_tile0, &ix->ws_units, &ix->d_tiles, &ix->d_tile_leaf, &ix->d_tile_row0, &ix->ws_lq_cnt, &ix->ws_lq_off, &ix->ws_lq_cursor, &ix->ws_leaf_queries,
                       &ix->ws_seed_cand, &ix->ws_seed_cnt, &ix->ws_seed_ids, &ix->ws_seed_scores, &ix->ws_emit, &ix->ws_emit_cnt,
                       &ix->d_base16, &ix->ws_q16, &ix->d_base16n, &ix->ws_q16n, &ix->d_base16e, &ix->ws_q16e, &ix->ws_flag, &ix->ws_qnorm, &ix->ws_tau, &ix->ws_slack};
     for (DevBuf *b : more) b->release();
@@ -891,7 +892,14 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     }
     if ((int32_t)(ix->pinned[1] & 0xffffffff) != 0) return DPF_OK;     // overflow: gather path decides
 
-    fill_rerank_params(ix, rp, qpad, k, nullptr, ix->ws_emit_cnt.as<int32_t>(), ix->ws_emit.as<int32_t>(), d_ids, d_scores);
+    // distinct ids of every forward list (a row is forwarded once per tree it was found in)
+    const bool dedupe = 2 * (size_t)EMIT_CAP * 4 <= 128 * 1024;       // the table of the longest possible list fits LDS
+    if (dedupe) {
+        HIPCHECK(ix, ix->ws_emit_ucnt.ensure((size_t)nq * 4));
+        launch_unique_lists(ix->ws_emit.as<int32_t>(), ix->ws_emit_cnt.as<int32_t>(), EMIT_CAP, ix->ws_emit_ucnt.as<int32_t>(), nq, stream);
+    }
+    fill_rerank_params(ix, rp, qpad, k, nullptr, dedupe ? ix->ws_emit_ucnt.as<int32_t>() : ix->ws_emit_cnt.as<int32_t>(),
+                       ix->ws_emit.as<int32_t>(), d_ids, d_scores);
     rp.cand_stride = EMIT_CAP;
     HIPCHECK(ix, hipEventRecord(ix->ev[4], stream));
     launch_rerank(ix->cfg.dtype, ix->cfg.metric, rp, nq, stream);

@@ -140,6 +140,7 @@ void launch_rows_to_f16(const float *src, int64_t src_stride, int dim, int64_t n
 void launch_tau(int metric, const double *seed_scores, const int32_t *seed_ids, int k, int64_t nq, float delta,
                 float maxnorm, const float *qnorm, int32_t *tau, float *slack, hipStream_t stream);
 void launch_qnorm(const float *Q, int64_t q_stride, int64_t nq, float *out, hipStream_t stream);
+void launch_unique_lists(int32_t *emit, const int32_t *emit_cnt, int32_t cap, int32_t *unique_cnt, int64_t nq, hipStream_t stream);
 void launch_overflow_flag(const int32_t *emit_cnt, int64_t nq, int32_t cap, int32_t *flag, hipStream_t stream);
 void launch_scan_i64(const int64_t *in, int64_t n, int64_t *off, hipStream_t stream);
 void launch_scan_i32(const int32_t *in, int64_t n, int64_t *off, hipStream_t stream);

@@ -1809,6 +1809,58 @@ void launch_overflow_flag(const int32_t *emit_cnt, int64_t nq, int32_t cap, int3
     hipLaunchKernelGGL(k_overflow_flag, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, stream, emit_cnt, nq, cap, flag);
 }
 
+// k_unique_lists: the scan forwards a row once per tree it was found in (near neighbours sit in
+// many trees); before the exact rerank gathers 400-byte rows for them, each query's forward list is
+// reduced to its distinct ids.  One workgroup per query: the ids go into an open-addressing table
+// in LDS (twice the list length, a power of two), then the occupied entries are written back over
+// the list (order does not matter: the rerank orders by score, then id).
+__global__ __launch_bounds__(256) void k_unique_lists(int32_t *__restrict__ emit, const int32_t *__restrict__ emit_cnt, int32_t cap,
+                                                      int32_t *__restrict__ unique_cnt)
+{
+    extern __shared__ int32_t tab[];
+    __shared__ int32_t s_out;
+    const int64_t q = blockIdx.x;
+    const int n = min(emit_cnt[q], cap);
+    int32_t *list = emit + (size_t)q * cap;
+    if (n <= 1) { if (threadIdx.x == 0) unique_cnt[q] = n; return; }
+    int T = 2;
+    while (T < 2 * n) T <<= 1;
+    for (int i = threadIdx.x; i < T; i += 256) tab[i] = -1;
+    if (threadIdx.x == 0) s_out = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int32_t id = list[i];                       // ids are row numbers: never -1
+        uint32_t h = ((uint32_t)id * 2654435761u) & (uint32_t)(T - 1);
+        for (;;) {
+            const int32_t old = atomicCAS(&tab[h], -1, id);
+            if (old == -1 || old == id) break;
+            h = (h + 1) & (uint32_t)(T - 1);
+        }
+    }
+    __syncthreads();                                      // the list has been read; it is overwritten below
+    const int lane = threadIdx.x & 63;
+    for (int i0 = (threadIdx.x & ~63); i0 < T; i0 += 256) {
+        const int32_t id = tab[i0 + lane];                // T is a multiple of 64 or smaller than the first stride
+        const bool have = i0 + lane < T && id != -1;
+        const unsigned long long m = __ballot(have);
+        if (m == 0) continue;
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&s_out, (int)__popcll(m));
+        base = __shfl(base, 0);
+        if (have) list[base + __popcll(m & ((1ull << lane) - 1ull))] = id;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) unique_cnt[q] = s_out;
+}
+
+void launch_unique_lists(int32_t *emit, const int32_t *emit_cnt, int32_t cap, int32_t *unique_cnt, int64_t nq, hipStream_t stream)
+{
+    if (nq <= 0) return;
+    int T = 2;
+    while (T < 2 * cap) T <<= 1;
+    hipLaunchKernelGGL(k_unique_lists, dim3((unsigned)nq), dim3(256), (size_t)T * 4, stream, emit, emit_cnt, cap, unique_cnt);
+}
+
 // ---------------------------------------------------------------------------
 // k_merge_topk: one thread per query merges `parts` sorted lists of k entries
 // ---------------------------------------------------------------------------
@@ -1863,6 +1915,8 @@ int configure_kernels()
     e = hipFuncSetAttribute((const void *)k_hash<double, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute((const void *)k_probe<1>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void *)k_unique_lists, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
     if (e != hipSuccess) return (int)e;
     return 0;
 }
