@@ -65,14 +65,12 @@ struct dpf_index {
     DevBuf d_leaf_tile0, ws_units;           // first tile of each bucket; work units of the batch
     int num_cus = 256;
     DevBuf d_tiles;                          // {bucket, first id slot, rows, 0} per tile
-    DevBuf d_tile_leaf, d_tile_row0;         // 64-row tiles of the buckets (bucket-major scan)
     DevBuf d_base16e, ws_q16e;               // distances between the rows and their fp16 copies
     DevBuf d_base16n, ws_q16n;               // their squared norms
     DevBuf d_base16, ws_q16;                 // fp16 copies of the resident rows / of the query batch
     int ks16 = -1;                           // 32-dimension fp16 steps per padded row (-1: no fp16 scan)
     int64_t ntiles = 0, nutiles = 0, num_leaves = 0;
     std::vector<uint32_t> h_leaf_len;        // rows per bucket of the uploaded snapshot
-    double maxnorm = 0.0;                    // largest base-row norm seen by dpf_fit
     bool bucket_major = false;               // the bucket-major rerank applies to this handle
     bool fitted = false;
     dpf_stats st{};
@@ -82,7 +80,7 @@ struct dpf_index {
     DevBuf ws_hq, ws_hqids, ws_hids, ws_hscores;     // device copies for the host-pointer entry points
     DevBuf ws_stage;                                  // fit staging
     DevBuf ws_lq_cnt, ws_lq_off, ws_lq_cursor, ws_leaf_queries, ws_seed_cand, ws_seed_cnt, ws_seed_ids,
-        ws_seed_scores, ws_emit, ws_emit_cnt, ws_flag, ws_qnorm, ws_tau, ws_slack;
+        ws_seed_scores, ws_emit, ws_emit_cnt, ws_flag, ws_tau;
     hipEvent_t ev_scan[4]{};                          // first and second pass of the scan
     int scan_launches = 0;
     unsigned long long *d_short_hash = nullptr;
@@ -156,9 +154,9 @@ extern "C" int dpf_create(const dpf_config *cfg, dpf_index **out)
     const int64_t per16 = 16 / (int64_t)ix->elem;
     ix->dpad = (cfg->dim + per16 - 1) / per16 * per16;
     if (cfg->dtype == DPF_F32 && !(cfg->flags & DPF_FLAG_GATHER_ONLY) && !getenv("DPF_GATHER_ONLY")) {
-        // rows padded to a piece count the bucket-major scan is instantiated for
-        const int nc = leafscan_padded_chunks((int)(ix->dpad / 4));
-        if (nc > 0) { ix->dpad = (int64_t)nc * 4; ix->bucket_major = true; ix->ks16 = leafscan_f16_steps(cfg->dim); }
+        // the bucket-major scan works on fp16 copies of up to 256 dimensions
+        ix->ks16 = leafscan_f16_steps(cfg->dim);
+        ix->bucket_major = ix->ks16 > 0;
     }
     if (ix->dpad * (int64_t)ix->elem / 16 > rerank_max_chunks16()) { delete ix; return fail(nullptr, DPF_EINVAL, "dpf_create: dim too large for the rerank kernel"); }
     resolve_rows(ix);
@@ -212,9 +210,9 @@ extern "C" void dpf_destroy(dpf_index *ix)
     if (ix->pinned) (void)hipHostFree(ix->pinned);
     for (int i = 0; i < 6; i++) if (ix->ev[i]) (void)hipEventDestroy(ix->ev[i]);
     for (int i = 0; i < 4; i++) if (ix->ev_scan[i]) (void)hipEventDestroy(ix->ev_scan[i]);
-    DevBuf *more[] = {&ix->ws_emit_ucnt, &ix->ws_emit_v, &ix->ws_leaf_units, &ix->ws_unit_off, &ix->ws_q_leaves, &ix->ws_q_leaf_cnt, &ix->d_leaf_tile0, &ix->ws_units, &ix->d_tiles, &ix->d_tile_leaf, &ix->d_tile_row0, &ix->ws_lq_cnt, &ix->ws_lq_off, &ix->ws_lq_cursor, &ix->ws_leaf_queries,
+    DevBuf *more[] = {&ix->ws_emit_ucnt, &ix->ws_emit_v, &ix->ws_leaf_units, &ix->ws_unit_off, &ix->ws_q_leaves, &ix->ws_q_leaf_cnt, &ix->d_leaf_tile0, &ix->ws_units, &ix->d_tiles, &ix->ws_lq_cnt, &ix->ws_lq_off, &ix->ws_lq_cursor, &ix->ws_leaf_queries,
                       &ix->ws_seed_cand, &ix->ws_seed_cnt, &ix->ws_seed_ids, &ix->ws_seed_scores, &ix->ws_emit, &ix->ws_emit_cnt,
-                      &ix->d_base16, &ix->ws_q16, &ix->d_base16n, &ix->ws_q16n, &ix->d_base16e, &ix->ws_q16e, &ix->ws_flag, &ix->ws_qnorm, &ix->ws_tau, &ix->ws_slack};
+                      &ix->d_base16, &ix->ws_q16, &ix->d_base16n, &ix->ws_q16n, &ix->d_base16e, &ix->ws_q16e, &ix->ws_flag, &ix->ws_tau};
     for (DevBuf *b : more) b->release();
     delete ix;
 }
@@ -333,16 +331,12 @@ static int upload_snapshot(dpf_index *ix, ForestSnapshot &s)
         s.ids.swap(ids);
         s.leaf_off.swap(off);
     }
-    std::vector<uint32_t> tile_leaf, tile_row0, tiles, leaf_tile0(s.leaf_off.size(), 0u);
-    const uint32_t TR = 64;                               // rows per work-unit tile of the fp16 scan
+    std::vector<uint32_t> tiles, leaf_tile0(s.leaf_off.size(), 0u);
+    const uint32_t TR = 64;                               // rows per work-unit tile of the scan
     for (size_t l = 0; l + 1 < s.leaf_off.size(); l++) {
         const uint32_t len = s.leaf_off[l + 1] - s.leaf_off[l];
         leaf_tile0[l] = (uint32_t)(tiles.size() / 4);
-        for (uint32_t r = 0; r < len; r += 64) {          // 64-row tiles of the fp32 engines
-            tile_leaf.push_back((uint32_t)l);
-            tile_row0.push_back(r);
-        }
-        for (uint32_t r = 0; r < len; r += TR) {          // work-unit tiles of the fp16 scan
+        for (uint32_t r = 0; r < len; r += TR) {          // work-unit tiles of the scan
             tiles.push_back((uint32_t)l); tiles.push_back(s.leaf_off[l] + r); tiles.push_back(std::min<uint32_t>(TR, len - r)); tiles.push_back(0u);
         }
     }
@@ -352,10 +346,8 @@ static int upload_snapshot(dpf_index *ix, ForestSnapshot &s)
     if ((rc = upload(ix, ix->d_leaf_tile0, leaf_tile0)) != DPF_OK) return rc;
     ix->h_leaf_len.resize(s.leaf_off.size() - 1);
     for (size_t l = 0; l + 1 < s.leaf_off.size(); l++) ix->h_leaf_len[l] = s.leaf_off[l + 1] - s.leaf_off[l];
-    ix->ntiles = (int64_t)tile_leaf.size();
+    ix->ntiles = ix->nutiles;
     ix->num_leaves = (int64_t)s.leaf_off.size() - 1;
-    if ((rc = upload(ix, ix->d_tile_leaf, tile_leaf)) != DPF_OK) return rc;
-    if ((rc = upload(ix, ix->d_tile_row0, tile_row0)) != DPF_OK) return rc;
     if ((rc = upload(ix, ix->d_roots, s.roots)) != DPF_OK) return rc;
     if ((rc = upload(ix, ix->d_dnodes, s.dnodes)) != DPF_OK) return rc;
     if ((rc = upload(ix, ix->d_leaf_off, s.leaf_off)) != DPF_OK) return rc;
@@ -437,18 +429,6 @@ extern "C" int dpf_fit(dpf_index *ix, const void *X, int64_t n)
     }
     ix->h_hashes.resize((size_t)total * L);
     ix->h_parts.resize((size_t)total * L);
-    if (ix->bucket_major && c.metric == DPF_METRIC_DOT) {
-        // bound of the fp32 filter's rounding error for inner products (dtype is f32 here)
-        const float *xf = (const float *)X;
-        double mx = ix->maxnorm * ix->maxnorm;
-        for (int64_t i = 0; i < n; i++) {
-            double sq = 0;
-            for (int k = 0; k < d; k++) sq += (double)xf[i * d + k] * (double)xf[i * d + k];
-            mx = std::max(mx, sq);
-        }
-        ix->maxnorm = std::sqrt(mx);
-    }
-
     const int64_t batch = 1 << 17;
     HIPCHECK(ix, ix->ws_stage.ensure((size_t)std::min<int64_t>(batch, std::max<int64_t>(n, 1)) * d * ix->elem));
     HIPCHECK(ix, ix->ws_hashes.ensure((size_t)std::min<int64_t>(batch, std::max<int64_t>(n, 1)) * L * 4));
@@ -519,7 +499,7 @@ extern "C" int dpf_save(dpf_index *ix, const char *path)
     w.put(SNAP_MAGIC, 8);
     w.val(ix->cfg);
     w.put(ix->hp.sampling_index, sizeof(ix->hp.sampling_index));
-    w.val(ix->n); w.val(ix->base_rows); w.val(ix->maxnorm);
+    w.val(ix->n); w.val(ix->base_rows);
     w.vec(ix->fns); w.vec(ix->chain_fn); w.vec(ix->b); w.vec(ix->w);
     w.vec(ix->part_fns); w.vec(ix->part_b); w.vec(ix->part_w);
     w.vec(ix->h_hashes); w.vec(ix->h_parts);
@@ -552,10 +532,9 @@ extern "C" int dpf_load(const char *path, int32_t device, dpf_index **out)
     dpf_config cfg{};
     int32_t si[32];
     int64_t n = 0, base_rows = 0;
-    double maxnorm = 0;
     r.get(magic, 8);
     if (!r.ok || memcmp(magic, SNAP_MAGIC, 8) != 0) { fclose(f); return fail(nullptr, DPF_EINVAL, "dpf_load: not a snapshot file of this library version"); }
-    r.val(cfg); r.get(si, sizeof(si)); r.val(n); r.val(base_rows); r.val(maxnorm);
+    r.val(cfg); r.get(si, sizeof(si)); r.val(n); r.val(base_rows);
     if (!r.ok || n < 0 || base_rows < 0 || base_rows > n) { fclose(f); return fail(nullptr, DPF_EINVAL, "dpf_load: damaged header"); }
     if (device >= 0) cfg.device = device;
     dpf_index *ix = nullptr;
@@ -599,7 +578,6 @@ extern "C" int dpf_load(const char *path, int32_t device, dpf_index **out)
     fclose(f);
     ix->h_hashes.swap(hh);
     ix->h_parts.swap(hp);
-    ix->maxnorm = maxnorm;
     if ((rc = finish_fit(ix, n, base_rows)) != DPF_OK) { g_create_error = "dpf_load: " + ix->err; dpf_destroy(ix); return rc; }
     *out = ix;
     return DPF_OK;
@@ -743,9 +721,7 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     HIPCHECK(ix, ix->ws_emit.ensure((size_t)nq * EMIT_CAP * 4));
     HIPCHECK(ix, ix->ws_emit_cnt.ensure((size_t)nq * 4));
     HIPCHECK(ix, ix->ws_flag.ensure(16));
-    HIPCHECK(ix, ix->ws_qnorm.ensure((size_t)nq * 4));
     HIPCHECK(ix, ix->ws_tau.ensure((size_t)nq * 4));
-    HIPCHECK(ix, ix->ws_slack.ensure((size_t)nq * 4));
 
     if (ix->profiling) HIPCHECK(ix, hipEventRecord(ix->ev[0], stream));
     launch_hash(ix->cfg.dtype, qpad, qstride, nq, ix->hp, ix->ws_hashes.as<int32_t>(), ix->ws_parts.as<int32_t>(), stream);
@@ -772,15 +748,11 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     }
     launch_probe(0, pp, nq, stream);
     launch_scan_i32(ix->ws_lq_cnt.as<int32_t>(), nl, ix->ws_lq_off.as<int64_t>(), stream);
-    const int engine = [&] { const char *e = getenv("DPF_LEAFSCAN"); return (e && !strcmp(e, "valu")) ? 0 : ((e && !strcmp(e, "f32")) || ix->ks16 < 0 ? 1 : 2); }();
-    ix->pinned[2] = 0;
-    if (engine == 2) {
-        HIPCHECK(ix, ix->ws_leaf_units.ensure((size_t)(nl + 1) * 4));
-        HIPCHECK(ix, ix->ws_unit_off.ensure((size_t)(nl + 2) * 8));
-        launch_unit_count(ix->ws_lq_cnt.as<uint32_t>(), ix->d_leaf_tile0.as<uint32_t>(), nl, ix->ws_leaf_units.as<int32_t>(),
-                          ix->ws_unit_off.as<int64_t>(), stream);
-        HIPCHECK(ix, hipMemcpyAsync(ix->pinned + 2, ix->ws_unit_off.as<int64_t>() + nl, 8, hipMemcpyDeviceToHost, stream));
-    }
+    HIPCHECK(ix, ix->ws_leaf_units.ensure((size_t)(nl + 1) * 4));
+    HIPCHECK(ix, ix->ws_unit_off.ensure((size_t)(nl + 2) * 8));
+    launch_unit_count(ix->ws_lq_cnt.as<uint32_t>(), ix->d_leaf_tile0.as<uint32_t>(), nl, ix->ws_leaf_units.as<int32_t>(),
+                      ix->ws_unit_off.as<int64_t>(), stream);
+    HIPCHECK(ix, hipMemcpyAsync(ix->pinned + 2, ix->ws_unit_off.as<int64_t>() + nl, 8, hipMemcpyDeviceToHost, stream));
     HIPCHECK(ix, hipMemcpyAsync(ix->pinned, ix->ws_lq_off.as<int64_t>() + nl, 8, hipMemcpyDeviceToHost, stream));
     HIPCHECK(ix, hipMemcpyAsync(ix->pinned + 3, pp.q_leaf_overflow, 4, hipMemcpyDeviceToHost, stream));
     HIPCHECK(ix, hipStreamSynchronize(stream));
@@ -822,62 +794,47 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
                        ix->ws_seed_ids.as<int32_t>(), ix->ws_seed_scores.as<double>());
     rp.cand_stride = SEED_CAP;
     launch_rerank(ix->cfg.dtype, ix->cfg.metric, rp, nq, stream);
-    if (ix->cfg.metric == DPF_METRIC_DOT) launch_qnorm((const float *)qpad, ix->dpad, nq, ix->ws_qnorm.as<float>(), stream);
+    launch_tau(ix->cfg.metric, ix->ws_seed_scores.as<double>(), ix->ws_seed_ids.as<int32_t>(), k, nq, ix->ws_tau.as<int32_t>(), stream);
 
+    // fp16 copies of the queries, the work list, the scan
+    HIPCHECK(ix, ix->ws_q16.ensure((size_t)nq * ix->ks16 * 32 * 2));
+    HIPCHECK(ix, ix->ws_q16n.ensure((size_t)nq * 4));
+    HIPCHECK(ix, ix->ws_q16e.ensure((size_t)nq * 4));
+    launch_rows_to_f16((const float *)qpad, ix->dpad, ix->cfg.dim, nq, ix->ws_q16.as<uint16_t>(), ix->ks16 * 32,
+                       ix->ws_q16n.as<float>(), ix->ws_q16e.as<float>(), stream);
+    HIPCHECK(ix, ix->ws_units.ensure((size_t)std::max<int64_t>(nunits, 1) * 16));
+    launch_units(ix->ws_lq_cnt.as<uint32_t>(), ix->ws_lq_off.as<int64_t>(), ix->d_leaf_tile0.as<uint32_t>(),
+                 (const uint4 *)ix->d_tiles.p, nl, ix->ws_unit_off.as<int64_t>(), (uint4 *)ix->ws_units.p, stream);
+    HIPCHECK(ix, ix->ws_emit_v.ensure((size_t)nq * EMIT_CAP * 4));
     LeafScanParams lp;
-    lp.tiles = (const uint4 *)ix->d_tiles.p;
-    lp.tile_leaf = ix->d_tile_leaf.as<uint32_t>(); lp.tile_row0 = ix->d_tile_row0.as<uint32_t>(); lp.ntiles = ix->ntiles;
-    lp.leaf_off = ix->d_leaf_off.as<uint32_t>(); lp.ids = ix->d_ids.as<int32_t>();
-    lp.lq_off = ix->ws_lq_off.as<int64_t>(); lp.leaf_queries = ix->ws_leaf_queries.as<int32_t>();
-    lp.base = ix->d_base.as<float>(); lp.base_stride = ix->dpad;
+    lp.ids = ix->d_ids.as<int32_t>();
+    lp.leaf_queries = ix->ws_leaf_queries.as<int32_t>();
     lp.row_begin = ix->row_begin; lp.row_end = ix->row_begin + ix->base_rows;
-    lp.Q = (const float *)qpad; lp.q_stride = ix->dpad;
     lp.qids = d_qids; lp.exclude_self = ix->cfg.exclude_self;
-    launch_tau(ix->cfg.metric, ix->ws_seed_scores.as<double>(), ix->ws_seed_ids.as<int32_t>(), k, nq,
-               (float)((double)(ix->dpad + 8) * std::ldexp(1.0, -23)), (float)(ix->maxnorm * 1.0001),
-               ix->ws_qnorm.as<float>(), ix->ws_tau.as<int32_t>(), ix->ws_slack.as<float>(), stream);
     lp.tau = ix->ws_tau.as<int32_t>();
-    lp.slack = ix->cfg.metric == DPF_METRIC_DOT ? ix->ws_slack.as<float>() : nullptr;
     lp.k = k;
-    lp.delta = (float)((double)(ix->dpad + 8) * std::ldexp(1.0, -23));
-    lp.engine = engine;
-    lp.ks = ix->ks16; lp.base16 = ix->d_base16.as<uint16_t>(); lp.Q16 = nullptr;
-    if (lp.engine == 2) {
-        HIPCHECK(ix, ix->ws_q16.ensure((size_t)nq * ix->ks16 * 32 * 2));
-        HIPCHECK(ix, ix->ws_q16n.ensure((size_t)nq * 4));
-        HIPCHECK(ix, ix->ws_q16e.ensure((size_t)nq * 4));
-        launch_rows_to_f16((const float *)qpad, ix->dpad, ix->cfg.dim, nq, ix->ws_q16.as<uint16_t>(), ix->ks16 * 32,
-                            ix->ws_q16n.as<float>(), ix->ws_q16e.as<float>(), stream);
-        lp.q16_norm = ix->ws_q16n.as<float>(); lp.q16_err = ix->ws_q16e.as<float>(); lp.base16_norm = ix->d_base16n.as<float>();
-        lp.Q16 = ix->ws_q16.as<uint16_t>();
-        HIPCHECK(ix, ix->ws_units.ensure((size_t)std::max<int64_t>(nunits, 1) * 16));
-        launch_units(ix->ws_lq_cnt.as<uint32_t>(), ix->ws_lq_off.as<int64_t>(), ix->d_leaf_tile0.as<uint32_t>(),
-                     (const uint4 *)ix->d_tiles.p, nl, ix->ws_unit_off.as<int64_t>(), (uint4 *)ix->ws_units.p, stream);
-        lp.units = (const uint4 *)ix->ws_units.p; lp.unit_begin = 0; lp.unit_end = nunits; lp.num_cus = ix->num_cus;
-        HIPCHECK(ix, ix->ws_emit_v.ensure((size_t)nq * EMIT_CAP * 4));
-        lp.emit_v = ix->ws_emit_v.as<float>();
-    }
+    lp.emit = ix->ws_emit.as<int32_t>(); lp.emit_v = ix->ws_emit_v.as<float>();
+    lp.emit_cnt = ix->ws_emit_cnt.as<int32_t>(); lp.emit_cap = EMIT_CAP;
     lp.debug = getenv("DPF_LS_DEBUG") ? atoi(getenv("DPF_LS_DEBUG")) : 0;
-    lp.emit = ix->ws_emit.as<int32_t>(); lp.emit_cnt = ix->ws_emit_cnt.as<int32_t>(); lp.emit_cap = EMIT_CAP;
+    lp.Q16 = ix->ws_q16.as<uint16_t>(); lp.base16 = ix->d_base16.as<uint16_t>();
+    lp.q16_norm = ix->ws_q16n.as<float>(); lp.base16_norm = ix->d_base16n.as<float>(); lp.q16_err = ix->ws_q16e.as<float>();
+    lp.units = (const uint4 *)ix->ws_units.p;
+    lp.num_cus = ix->num_cus; lp.ks = ix->ks16;
+    // a first slice of the units, then thresholds refined from what it forwarded, then the rest
+    static const int first_permille = getenv("DPF_FIRST_PASS") ? atoi(getenv("DPF_FIRST_PASS")) : 100;
+    const int64_t n_first = std::min<int64_t>(nunits, nunits * first_permille / 1000);
     ix->scan_launches = 1;
+    lp.unit_begin = 0; lp.unit_end = n_first;
     HIPCHECK(ix, hipEventRecord(ix->ev_scan[0], stream));
-    if (engine == 2) {
-        // a first slice of the units, then thresholds refined from what it forwarded, then the rest
-        static const int first_permille = getenv("DPF_FIRST_PASS") ? atoi(getenv("DPF_FIRST_PASS")) : 100;
-        const int64_t n_first = std::min<int64_t>(nunits, nunits * first_permille / 1000);
-        lp.unit_end = n_first;
-        launch_leafscan(ix->cfg.metric, (int)(ix->dpad / 4), lp, stream);
-        HIPCHECK(ix, hipEventRecord(ix->ev_scan[1], stream));
-        if (n_first > 0) {
-            launch_refine(ix->cfg.metric, lp.emit, lp.emit_v, lp.emit_cnt, EMIT_CAP, k, nq, lp.q16_err, lp.tau, stream);
-            ix->scan_launches = 2;
-        }
-        lp.unit_begin = n_first; lp.unit_end = nunits;
-    } else {
-        HIPCHECK(ix, hipEventRecord(ix->ev_scan[1], stream));
+    launch_leafscan(ix->cfg.metric, lp, stream);
+    HIPCHECK(ix, hipEventRecord(ix->ev_scan[1], stream));
+    if (n_first > 0) {
+        launch_refine(ix->cfg.metric, lp.emit, lp.emit_v, lp.emit_cnt, EMIT_CAP, k, nq, lp.q16_err, lp.tau, stream);
+        ix->scan_launches = 2;
     }
+    lp.unit_begin = n_first; lp.unit_end = nunits;
     HIPCHECK(ix, hipEventRecord(ix->ev_scan[2], stream));
-    launch_leafscan(ix->cfg.metric, (int)(ix->dpad / 4), lp, stream);
+    launch_leafscan(ix->cfg.metric, lp, stream);
     HIPCHECK(ix, hipEventRecord(ix->ev_scan[3], stream));
     launch_overflow_flag(ix->ws_emit_cnt.as<int32_t>(), nq, EMIT_CAP, ix->ws_flag.as<int32_t>(), stream);
     HIPCHECK(ix, hipMemcpyAsync(ix->pinned + 1, ix->ws_flag.p, 4, hipMemcpyDeviceToHost, stream));
@@ -1168,7 +1125,7 @@ extern "C" int dpf_last_rerank_profile(dpf_index *ix, double *ms, int64_t *algor
         int64_t touched_rows = 0;
         for (size_t l = 0; l < c.size(); l++)
             if (c[l]) touched_rows += ix->h_leaf_len[l];
-        const int64_t srow = ix->ks16 > 0 && !getenv("DPF_LEAFSCAN") ? (int64_t)ix->ks16 * 64 : ix->dpad * 4;
+        const int64_t srow = (int64_t)ix->ks16 * 64;
         if (algorithmic_bytes) *algorithmic_bytes = touched_rows * (srow + 4) + ix->st.last_pairs * (srow + 12) + uniq * 8;
         return DPF_OK;
     }

@@ -67,38 +67,25 @@ struct ProbeParams {
 // Bucket-major scan: every touched bucket's rows are loaded once and scored
 // against all the queries that probe that bucket.
 struct LeafScanParams {
-    const uint32_t *tile_leaf;   // [ntiles] bucket of each 64-row tile
-    const uint32_t *tile_row0;   // [ntiles] first row of the tile inside its bucket
-    const uint4 *tiles;          // [ntiles] {bucket, first slot in ids[], rows in the tile, 0}
-    int64_t ntiles;
-    const uint32_t *leaf_off;
-    const int32_t *ids;
-    const int64_t *lq_off;
-    const int32_t *leaf_queries;
-    const float *base;           // padded rows of the resident shard
-    int64_t base_stride;         // floats
+    const int32_t *ids;          // bucket contents (shard-filtered)
+    const int32_t *leaf_queries; // the queries probing each bucket, bucket-major
     int64_t row_begin, row_end;
-    const float *Q;              // padded query rows
-    int64_t q_stride;            // floats
     const int32_t *qids;
     int32_t exclude_self;
-    int32_t *tau;                // [nq] filter threshold on the fp32 score, order-preserving int encoding; tightened in flight
-    const float *slack;          // [nq] absolute rounding slack (dot metric) or nullptr
+    int32_t *tau;                // [nq] filter threshold on the score, order-preserving int encoding; tightened in flight
     int32_t k;
-    float delta;                 // relative rounding bound of the fp32 score
-    int32_t *emit;               // [nq][emit_cap]
+    int32_t *emit;               // [nq][emit_cap] forwarded ids
+    float *emit_v;               // [nq][emit_cap] pessimistic score bound of each forwarded row
     int32_t *emit_cnt;           // [nq] may exceed emit_cap: overflow
     int32_t emit_cap;
     int32_t debug;               // ablation switch for measurements (0 in production)
-    int32_t engine;              // 0 = vector ALU (lane per row), 1 = f32 MFMA 16x16x4, 2 = fp16 MFMA 16x16x32
-    const uint16_t *Q16;         // fp16 copies (engine 2): queries [nq][ks*32], rows [rows][ks*32]
+    const uint16_t *Q16;         // fp16 copies: queries [nq][ks*32], rows [rows][ks*32]
     const uint16_t *base16;
     const float *q16_norm;       // [nq] / [rows] squared norms of the fp16 copies (fp32 sums)
     const float *base16_norm;
     const float *q16_err;        // [nq] upper bounds of |q - q~|
-    const uint4 *units;          // work units of the batch (engine 2), see k_units
+    const uint4 *units;          // work units of the batch, see k_units
     int64_t unit_begin, unit_end; // the slice of units[] this launch works through
-    float *emit_v;               // [nq][emit_cap] pessimistic score bound of each forwarded row (engine 2)
     int32_t num_cus;
     int32_t ks;
 };
@@ -124,8 +111,7 @@ void launch_hash(int dtype, const void *X, int64_t x_stride, int64_t n, const Ha
 size_t hash_shmem_bytes(const HashParams &p);
 void launch_probe(int mode, const ProbeParams &p, int64_t nq, hipStream_t stream);
 void launch_fill_lists(const ProbeParams &p, int64_t nq, hipStream_t stream);
-void launch_leafscan(int metric, int chunks16, const LeafScanParams &p, hipStream_t stream);
-int leafscan_padded_chunks(int nc);
+void launch_leafscan(int metric, const LeafScanParams &p, hipStream_t stream);
 void launch_unit_count(const uint32_t *lq_cnt, const uint32_t *leaf_tile0, int64_t nl, int32_t *leaf_units, int64_t *unit_off,
                        hipStream_t stream);
 void launch_units(const uint32_t *lq_cnt, const int64_t *lq_off, const uint32_t *leaf_tile0, const uint4 *tiles, int64_t nl,
@@ -137,9 +123,7 @@ void launch_refine(int metric, const int32_t *emit, const float *emit_v, const i
                    const float *q16_err, int32_t *tau, hipStream_t stream);
 void launch_rows_to_f16(const float *src, int64_t src_stride, int dim, int64_t n, uint16_t *dst, int dst_stride,
                          float *norms, float *errs, hipStream_t stream);
-void launch_tau(int metric, const double *seed_scores, const int32_t *seed_ids, int k, int64_t nq, float delta,
-                float maxnorm, const float *qnorm, int32_t *tau, float *slack, hipStream_t stream);
-void launch_qnorm(const float *Q, int64_t q_stride, int64_t nq, float *out, hipStream_t stream);
+void launch_tau(int metric, const double *seed_scores, const int32_t *seed_ids, int k, int64_t nq, int32_t *tau, hipStream_t stream);
 void launch_unique_lists(int32_t *emit, const int32_t *emit_cnt, int32_t cap, int32_t *unique_cnt, int64_t nq, hipStream_t stream);
 void launch_overflow_flag(const int32_t *emit_cnt, int64_t nq, int32_t cap, int32_t *flag, hipStream_t stream);
 void launch_scan_i64(const int64_t *in, int64_t n, int64_t *off, hipStream_t stream);

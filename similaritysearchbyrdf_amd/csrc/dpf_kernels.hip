@@ -32,9 +32,6 @@
 #ifndef LS16_WAVES4
 #define LS16_WAVES4 3
 #endif
-#ifndef LEAFSCAN_WAVES
-#define LEAFSCAN_WAVES 4
-#endif
 
 namespace dpf {
 
@@ -864,20 +861,19 @@ void launch_rerank(int dtype, int metric, const RerankParams &p, int64_t nq, hip
 }
 
 // ---------------------------------------------------------------------------
-// k_leafscan: bucket-major candidate filter
+// Bucket-major candidate filter
 // ---------------------------------------------------------------------------
 // The per-query gather above reads a bucket's rows once per query that probes
-// the bucket.  In a batch many queries probe the same buckets, so this kernel
-// turns the loop around: one wave owns a 64-row tile of one bucket (lane = row,
-// the row's dim floats live in registers), and walks the list of queries that
-// reach the bucket; each query row is a wave-uniform broadcast read.  The rows
-// come from HBM once per tile instead of once per (query, bucket).
+// the bucket.  In a batch many queries probe the same buckets, so the scan turns
+// the loop around: a wave owns a 64-row tile of one bucket and walks the list of
+// queries that reach the bucket.  The rows come from HBM once per tile instead of
+// once per (query, bucket).
 //
-// The score here is fp32 and only FILTERS: a row is forwarded to the exact fp64
-// rerank when its fp32 score is within the proven rounding bound of the
-// query's threshold, the exact k-th best score of a seed sample of the query's
-// own candidates (any subset's k-th best bounds the full set's k-th best).
-// Every true top-k member therefore survives; the exact kernel orders them.
+// The score here only FILTERS: a row is forwarded to the exact fp64 rerank when
+// its approximate score is within the proven error bound of the query's
+// threshold, an upper bound of the query's exact k-th best score (any subset's
+// k-th best bounds the full set's k-th best).  Every true top-k member therefore
+// survives; the exact kernel orders them.
 // order-preserving float <-> int32 (an involution), so thresholds can be tightened with integer atomics
 __device__ __host__ inline int32_t enc_f32(float f)
 {
@@ -890,311 +886,14 @@ __device__ inline float dec_f32(int32_t b)
     return __int_as_float(b >= 0 ? b : (b ^ 0x7fffffff));
 }
 
-template <int NC, int METRIC>
-__global__ __launch_bounds__(256, LEAFSCAN_WAVES) void k_leafscan(LeafScanParams p, const float *__restrict__ Qg,
-                                                                  const float *__restrict__ baseg)
-{
-    // forwarded (query, id) pairs are parked per wave and appended to the queries' lists 64 at a
-    // time, so the wave waits for one round of returning atomics per 64 pairs, not per pair
-    __shared__ int32_t s_fq[4][128], s_fid[4][128];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
-    if (tile >= p.ntiles) return;
-    const uint32_t leaf = p.tile_leaf[tile];
-    const int64_t lqb = p.lq_off[leaf], lqe = p.lq_off[leaf + 1];
-    if (lqb == lqe) return;
-    int nbuf = 0;                                  // wave-uniform fill of the parking buffer
-    auto flush = [&](int n) {
-        if (lane < n) {
-            const int32_t fq = s_fq[wave][lane];
-            const int at = atomicAdd(&p.emit_cnt[fq], 1);
-            if (at < p.emit_cap) p.emit[(size_t)fq * p.emit_cap + at] = s_fid[wave][lane];
-        }
-    };
-    const uint32_t beg = p.leaf_off[leaf] + p.tile_row0[tile];
-    const uint32_t end = p.leaf_off[leaf + 1];
-    const int32_t id = (beg + lane < end) ? p.ids[beg + lane] : -1;
-    const bool valid = id >= p.row_begin && id < p.row_end;
-    float4 x[NC];
-    {
-        const float4 *row = (const float4 *)(baseg + (size_t)(valid ? id - p.row_begin : 0) * p.base_stride);
-#pragma unroll
-        for (int c = 0; c < NC; c++) {
-            if (valid && p.debug != 2) x[c] = row[c];
-            else x[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    }
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    if (p.debug == 1) {         // rows only
-        float sacc = 0.f;
-#pragma unroll
-        for (int c = 0; c < NC; c++) sacc += x[c].x + x[c].y + x[c].z + x[c].w;
-        if (sacc == 1.2345e-30f) p.emit[0] = 1;
-        return;
-    }
-    for (int64_t q0 = lqb; q0 < lqe; q0 += 64) {
-        const int cnt = (int)((lqe - q0 < 64) ? lqe - q0 : 64);
-        const int32_t myq = lane < cnt ? p.leaf_queries[q0 + lane] : 0;
-        // per-lane prefetch of (threshold, id, slack) of the query this lane names
-        float mtau = 0.f, mslack = 0.f; int32_t mqid = -1;
-        if (lane < cnt) {
-            mtau = dec_f32(__hip_atomic_load(&p.tau[myq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            mqid = p.qids ? p.qids[myq] : -1;
-            mslack = p.slack ? p.slack[myq] : 0.f;
-        }
-        for (int j = 0; j < cnt; j++) {
-            const int32_t q = __builtin_amdgcn_readlane(myq, j);
-            const float tau = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mtau), j));
-            const int32_t qid = __builtin_amdgcn_readlane(mqid, j);
-            // wave-uniform row: scalar loads, operands straight from SGPRs
-            const float4 *qp = (const float4 *)(Qg + (size_t)q * p.q_stride);
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#pragma unroll
-            for (int c = 0; c < NC; c++) {
-                const float4 qv = qp[c];
-                if (METRIC == 1) {
-                    const float d0 = qv.x - x[c].x, d1 = qv.y - x[c].y, d2 = qv.z - x[c].z, d3 = qv.w - x[c].w;
-                    a0 = fmaf(d0, d0, a0); a1 = fmaf(d1, d1, a1); a2 = fmaf(d2, d2, a2); a3 = fmaf(d3, d3, a3);
-                } else {
-                    a0 = fmaf(qv.x, x[c].x, a0); a1 = fmaf(qv.y, x[c].y, a1);
-                    a2 = fmaf(qv.z, x[c].z, a2); a3 = fmaf(qv.w, x[c].w, a3);
-                }
-            }
-            const float score = (a0 + a1) + (a2 + a3);
-            bool pass = METRIC == 1 ? (score <= tau) : (score >= tau);
-            pass = pass && valid && !self_excluded(id, qid, p.exclude_self);
-            const unsigned long long m = __ballot(pass);
-            if (m) {
-                const int npass = __popcll(m);
-                if (npass >= p.k) {
-                    // >= k distinct rows of this bucket already beat the threshold: the k-th best of
-                    // them bounds the query's k-th best overall, so the threshold can only tighten
-                    int rank = 0;
-                    unsigned long long mm = m;
-                    while (mm) {
-                        const int src = __ffsll((long long)mm) - 1;
-                        mm &= mm - 1;
-                        const float o = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(score), src));
-                        const bool before = METRIC == 1 ? (o < score) : (o > score);
-                        rank += (before || (o == score && src < lane)) ? 1 : 0;
-                    }
-                    if (pass && rank == p.k - 1) {
-                        if (METRIC == 1) {
-                            // k rows have fp32 score <= t  =>  exact k-th best <= t/(1-delta)
-                            //   =>  every true member scores <= t (1+delta)/(1-delta)
-                            const float thr = score * (1.0f + 2.5f * p.delta) * (1.0f + 1e-6f);
-                            atomicMin(&p.tau[q], enc_f32(thr));
-                        } else {
-                            const float sl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mslack), j));
-                            const float thr = score - 2.5f * sl - fabsf(score) * 1e-6f;
-                            atomicMax(&p.tau[q], enc_f32(thr));
-                        }
-                    }
-                }
-                if (pass) {
-                    const int at = nbuf + __popcll(m & lt);
-                    s_fq[wave][at] = q;
-                    s_fid[wave][at] = id;
-                }
-                nbuf += npass;
-                if (nbuf >= 64) {
-                    flush(64);
-                    // move the tail (< 64 entries) to the front
-                    const int rest = nbuf - 64;
-                    int32_t tq = 0, ti = 0;
-                    if (lane < rest) { tq = s_fq[wave][64 + lane]; ti = s_fid[wave][64 + lane]; }
-                    if (lane < rest) { s_fq[wave][lane] = tq; s_fid[wave][lane] = ti; }
-                    nbuf = rest;
-                }
-            }
-        }
-    }
-    flush(nbuf);
-}
-
-// ---------------------------------------------------------------------------
-// k_leafscan_mfma: the same bucket-major filter on the matrix cores
-// ---------------------------------------------------------------------------
-// A wave owns a 64-row tile (four 16-row blocks) of one bucket and walks the
-// bucket's queries 16 at a time: scores[16 queries][16 rows] = Q . X^T is a
-// chain of v_mfma_f32_16x16x4_f32.  Neither operand is broadcast: lane
-// (i = lane & 15, g = lane >> 4) holds the 16-byte pieces g, g+4, g+8, ... of
-// vector i, for the query block (A operand) and for each row block (B operand)
-// alike, so MFMA step s multiplies the same dimensions on both sides.  The
-// accumulator leaves lane l with the dot products of row (l & 15) against the
-// queries 4*(l >> 4) + {0..3}.  Squared distances come from
-// |q|^2 + |x|^2 - 2 q.x; the cancellation this form adds is covered by an
-// absolute slack proportional to |q|^2 + |x|^2, so the filter stays
-// conservative and the exact fp64 rerank still decides the result.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-template <int NP, int METRIC>
-__global__ __launch_bounds__(256, 2) void k_leafscan_mfma(LeafScanParams p, const float *__restrict__ Qg,
-                                                          const float *__restrict__ baseg)
-{
-    __shared__ int32_t s_fq[4][128], s_fid[4][128];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
-    if (tile >= p.ntiles) return;
-    const uint32_t leaf = p.tile_leaf[tile];
-    const int64_t lqb = p.lq_off[leaf], lqe = p.lq_off[leaf + 1];
-    if (lqb == lqe) return;
-    const int i16 = lane & 15, g = lane >> 4;
-    const int nc = (int)(p.base_stride / 4);
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    const unsigned long long gmask = 0xffffull << (16 * g);
-    // absolute rounding slack of |q|^2 + |x|^2 - 2 q.x in fp32, per unit of (|q|^2 + |x|^2)
-    const float cslack = 3.0f * p.delta;
-
-    int nbuf = 0;
-    auto flush = [&](int n) {
-        if (lane < n) {
-            const int32_t fq = s_fq[wave][lane];
-            const int at = atomicAdd(&p.emit_cnt[fq], 1);
-            if (at < p.emit_cap) p.emit[(size_t)fq * p.emit_cap + at] = s_fid[wave][lane];
-        }
-    };
-
-    const uint32_t beg = p.leaf_off[leaf] + p.tile_row0[tile];
-    const uint32_t end = p.leaf_off[leaf + 1];
-    float4 xb[4][NP];
-    int32_t idj[4];
-    float xn[4];
-#pragma unroll
-    for (int rb = 0; rb < 4; rb++) {
-        const uint32_t idx = beg + rb * 16 + i16;
-        int32_t id = idx < end ? p.ids[idx] : -1;
-        if (!(id >= p.row_begin && id < p.row_end)) id = -1;
-        idj[rb] = id;
-        const float4 *row = (const float4 *)(baseg + (size_t)(id >= 0 ? id - p.row_begin : 0) * p.base_stride);
-        float s = 0.f;
-#pragma unroll
-        for (int t = 0; t < NP; t++) {
-            const int c = g + 4 * t;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (id >= 0 && c < nc) v = row[c];
-            xb[rb][t] = v;
-            s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-        }
-        s += __shfl_xor(s, 16);
-        s += __shfl_xor(s, 32);
-        xn[rb] = s;
-    }
-
-    for (int64_t q0 = lqb; q0 < lqe; q0 += 16) {
-        const int32_t qs = (q0 + i16 < lqe) ? p.leaf_queries[q0 + i16] : -1;
-        float4 qa[NP];
-        float qn_slot = 0.f;
-        {
-            const float4 *qrow = (const float4 *)(Qg + (size_t)(qs >= 0 ? qs : 0) * p.q_stride);
-#pragma unroll
-            for (int t = 0; t < NP; t++) {
-                const int c = g + 4 * t;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (qs >= 0 && c < nc) v = qrow[c];
-                qa[t] = v;
-                qn_slot += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-            }
-            qn_slot += __shfl_xor(qn_slot, 16);
-            qn_slot += __shfl_xor(qn_slot, 32);
-        }
-        // an empty slot never passes
-        float tau_slot = METRIC == 1 ? -HUGE_VALF : HUGE_VALF;
-        int32_t qid_slot = -1;
-        if (qs >= 0) {
-            tau_slot = dec_f32(__hip_atomic_load(&p.tau[qs], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            qid_slot = p.qids ? p.qids[qs] : -1;
-        }
-        f32x4 acc[4];
-#pragma unroll
-        for (int rb = 0; rb < 4; rb++) acc[rb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int t = 0; t < NP; t++) {
-            const float av[4] = {qa[t].x, qa[t].y, qa[t].z, qa[t].w};
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-#pragma unroll
-                for (int rb = 0; rb < 4; rb++) {
-                    const float bv = e == 0 ? xb[rb][t].x : (e == 1 ? xb[rb][t].y : (e == 2 ? xb[rb][t].z : xb[rb][t].w));
-                    acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv, acc[rb], 0, 0, 0);
-                }
-            }
-        }
-        // lane l now holds q(4g + r) . x(rb*16 + i16) in acc[rb][r]
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int slot = 4 * g + r;
-            const float tq = __shfl(tau_slot, slot);
-            const float qnq = __shfl(qn_slot, slot);
-            const int32_t qq = __shfl(qs, slot);
-            const int32_t qidq = __shfl(qid_slot, slot);
-            int tight = 0;
-#pragma unroll
-            for (int rb = 0; rb < 4; rb++) {
-                const float dotv = acc[rb][r];
-                float score, thr;
-                if (METRIC == 1) {
-                    score = (qnq + xn[rb]) - 2.0f * dotv;
-                    thr = tq + cslack * (qnq + xn[rb]);
-                } else {
-                    score = dotv;
-                    thr = tq;
-                }
-                const bool ok = idj[rb] >= 0 && qq >= 0 && !self_excluded(idj[rb], qidq, p.exclude_self);
-                const bool pass = ok && (METRIC == 1 ? (score <= thr) : (score >= thr));
-                if (METRIC == 1) {
-                    // rows whose EXACT distance is provably below 0.85 * threshold
-                    const bool deep = ok && (score + cslack * (qnq + xn[rb]) <= 0.85f * tq);
-                    tight += __popcll(__ballot(deep) & gmask);
-                }
-                const unsigned long long m = __ballot(pass);
-                if (m) {
-                    if (pass) {
-                        const int at = nbuf + __popcll(m & lt);
-                        s_fq[wave][at] = qq;
-                        s_fid[wave][at] = idj[rb];
-                    }
-                    nbuf += __popcll(m);
-                    if (nbuf >= 64) {
-                        flush(64);
-                        const int rest = nbuf - 64;
-                        int32_t tq2 = 0, ti2 = 0;
-                        if (lane < rest) { tq2 = s_fq[wave][64 + lane]; ti2 = s_fid[wave][64 + lane]; }
-                        if (lane < rest) { s_fq[wave][lane] = tq2; s_fid[wave][lane] = ti2; }
-                        nbuf = rest;
-                    }
-                }
-            }
-            if (METRIC == 1 && tight >= p.k && i16 == 0 && qq >= 0) {
-                // >= k distinct rows of this bucket are exactly closer than 0.85 * threshold: the
-                // query's k-th best is too, so 0.85 * threshold (plus rounding room) is a valid filter
-                const float thr = 0.85f * tq * (1.0f + p.delta) * (1.0f + 1e-6f);
-                atomicMin(&p.tau[qq], enc_f32(thr));
-            }
-        }
-    }
-    flush(nbuf);
-}
-
-template <int METRIC>
-static void launch_leafscan_mfma_m(int nc, const LeafScanParams &p, hipStream_t stream)
-{
-    dim3 grid((unsigned)((p.ntiles + 3) / 4)), block(256);
-#define DPF_LM(NP) hipLaunchKernelGGL((k_leafscan_mfma<NP, METRIC>), grid, block, 0, stream, p, p.Q, p.base)
-    if (nc <= 8) DPF_LM(2);
-    else if (nc <= 16) DPF_LM(4);
-    else if (nc <= 28) DPF_LM(7);
-    else DPF_LM(8);
-#undef DPF_LM
-}
 
 // ---------------------------------------------------------------------------
 // k_leafscan_f16: the bucket-major filter on an fp16 copy of the rows
 // ---------------------------------------------------------------------------
-// Same 64-row x 16-query tiling as k_leafscan_mfma, but both operands are fp16
-// (rows padded to KS*32 dimensions, 64*KS bytes, never straddling a 128-byte line)
-// and the products run on v_mfma_f32_16x16x32_f16: half the HBM bytes per row and
-// 1/7 of the matrix-core cycles.  The filter stays exact-safe because the rounding
+// 64-row x 16-query blocks of scores on v_mfma_f32_16x16x32_f16; both operands are
+// fp16 copies (rows padded to KS*32 dimensions, 64*KS bytes, never straddling a
+// 128-byte line): half the HBM bytes of the fp32 rows.  The filter stays exact-safe because the rounding
 // is MEASURED, not assumed: the conversion kernel stores |x - x~| per row (and per
 // query), so by the triangle inequality
 //     | |q~ - x~| - |q - x| | <= |q - q~| + |x - x~| =: eta,
@@ -1702,99 +1401,35 @@ void launch_rows_to_f16(const float *src, int64_t src_stride, int dim, int64_t n
                        dst, dst_stride, norms, errs);
 }
 
-// Filter thresholds on the fp32 score, from the exact k-th best of each query's seed sample.
-//   l2 : exact d <= kth and |score - d| <= delta * d           =>  score <= kth * (1 + delta)
-//   dot: |score - dot| <= delta * |q| * |x| <= delta*|q|*maxnorm =>  score >= kth - slack
+// First thresholds: the exact k-th best score of each query's seed sample, moved one rounding step
+// to the safe side by the conversion to fp32 (l2: up, dot: down).  A query with fewer than k seeds
+// starts without a threshold.
 template <int METRIC>
-__global__ void k_tau(const double *__restrict__ seed_scores, const int32_t *__restrict__ seed_ids, int k,
-                      int64_t nq, float delta, float maxnorm, const float *__restrict__ qnorm, int32_t *__restrict__ tau,
-                      float *__restrict__ slack_out)
+__global__ void k_tau(const double *__restrict__ seed_scores, const int32_t *__restrict__ seed_ids, int k, int64_t nq,
+                      int32_t *__restrict__ tau)
 {
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nq) return;
     const int32_t kth_id = seed_ids[q * k + k - 1];
     const double kth = seed_scores[q * k + k - 1];
     float t;
-    if (METRIC == 1) {
-        t = kth_id < 0 ? HUGE_VALF : (float)(kth * (1.0 + (double)delta)) * (1.0f + 1e-6f);
-    } else {
-        const float slack = delta * qnorm[q] * maxnorm * 1.0001f + 1e-30f;
-        t = kth_id < 0 ? -HUGE_VALF : (float)kth - slack - fabsf((float)kth) * 1e-6f;
-        slack_out[q] = slack;
-    }
+    if (METRIC == 1) t = kth_id < 0 ? HUGE_VALF : (float)kth * 1.000001f;
+    else t = kth_id < 0 ? -HUGE_VALF : (float)kth - fabsf((float)kth) * 1e-6f - 1e-30f;
     tau[q] = enc_f32(t);
 }
 
-void launch_tau(int metric, const double *seed_scores, const int32_t *seed_ids, int k, int64_t nq, float delta,
-                float maxnorm, const float *qnorm, int32_t *tau, float *slack, hipStream_t stream)
+void launch_tau(int metric, const double *seed_scores, const int32_t *seed_ids, int k, int64_t nq, int32_t *tau, hipStream_t stream)
 {
     if (nq <= 0) return;
     dim3 grid((unsigned)((nq + 255) / 256)), block(256);
-    if (metric == 0) hipLaunchKernelGGL((k_tau<0>), grid, block, 0, stream, seed_scores, seed_ids, k, nq, delta, maxnorm, qnorm, tau, slack);
-    else hipLaunchKernelGGL((k_tau<1>), grid, block, 0, stream, seed_scores, seed_ids, k, nq, delta, maxnorm, qnorm, tau, slack);
+    if (metric == 0) hipLaunchKernelGGL((k_tau<0>), grid, block, 0, stream, seed_scores, seed_ids, k, nq, tau);
+    else hipLaunchKernelGGL((k_tau<1>), grid, block, 0, stream, seed_scores, seed_ids, k, nq, tau);
 }
 
-template <int METRIC>
-static void launch_leafscan_m(int nc, const LeafScanParams &p, hipStream_t stream)
+void launch_leafscan(int metric, const LeafScanParams &p, hipStream_t stream)
 {
-    dim3 grid((unsigned)((p.ntiles + 3) / 4)), block(256);
-#define DPF_LS(NC) hipLaunchKernelGGL((k_leafscan<NC, METRIC>), grid, block, 0, stream, p, p.Q, p.base)
-    if (nc <= 4) DPF_LS(4);
-    else if (nc <= 8) DPF_LS(8);
-    else if (nc <= 13) DPF_LS(13);
-    else if (nc <= 16) DPF_LS(16);
-    else if (nc <= 20) DPF_LS(20);
-    else if (nc <= 25) DPF_LS(25);
-    else DPF_LS(32);
-#undef DPF_LS
-}
-
-// nc = 16-byte pieces per padded row; rows are read as NC pieces, NC >= nc, so the
-// caller pads base and query rows to leafscan_padded_chunks(nc) pieces.
-int leafscan_padded_chunks(int nc)
-{
-    if (nc <= 4) return 4;
-    if (nc <= 8) return 8;
-    if (nc <= 13) return 13;
-    if (nc <= 16) return 16;
-    if (nc <= 20) return 20;
-    if (nc <= 25) return 25;
-    return nc <= 32 ? 32 : -1;
-}
-
-void launch_leafscan(int metric, int chunks16, const LeafScanParams &p, hipStream_t stream)
-{
-    if (p.ntiles <= 0) return;
-    if (p.engine == 2) {
-        if (metric == 0) launch_leafscan_f16_m<0, 4>(p, stream);
-        else launch_leafscan_f16_m<1, 4>(p, stream);
-        return;
-    }
-    if (p.engine == 1) {
-        if (metric == 0) launch_leafscan_mfma_m<0>(chunks16, p, stream);
-        else launch_leafscan_mfma_m<1>(chunks16, p, stream);
-        return;
-    }
-    if (metric == 0) launch_leafscan_m<0>(chunks16, p, stream);
-    else launch_leafscan_m<1>(chunks16, p, stream);
-}
-
-// |q| of every (padded) query row, one wave per query
-__global__ void k_qnorm(const float *__restrict__ Q, int64_t q_stride, int64_t nq, float *__restrict__ out)
-{
-    const int lane = threadIdx.x & 63;
-    const int64_t q = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (q >= nq) return;
-    float s = 0.f;
-    for (int64_t i = lane; i < q_stride; i += 64) { const float v = Q[q * q_stride + i]; s += v * v; }
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if (lane == 0) out[q] = sqrtf(s) * 1.00001f;
-}
-
-void launch_qnorm(const float *Q, int64_t q_stride, int64_t nq, float *out, hipStream_t stream)
-{
-    if (nq <= 0) return;
-    hipLaunchKernelGGL(k_qnorm, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, stream, Q, q_stride, nq, out);
+    if (metric == 0) launch_leafscan_f16_m<0, 4>(p, stream);
+    else launch_leafscan_f16_m<1, 4>(p, stream);
 }
 
 __global__ void k_overflow_flag(const int32_t *__restrict__ emit_cnt, int64_t nq, int32_t cap, int32_t *flag)

@@ -296,10 +296,11 @@ def test_full_size_properties():
 
 
 @pytest.mark.parametrize("metric", ["l2", "dot"])
-@pytest.mark.parametrize("dim", [100, 50, 128, 24])
+@pytest.mark.parametrize("dim", [100, 50, 128, 24, 200, 256])
 def test_bucket_major_rerank_equals_gather_rerank(metric, dim):
-    # f32 handles rerank bucket-major (fp32 filter + exact fp64 rerank of the survivors); the
-    # per-query gather kernel scores every candidate in fp64.  Same ids, same scores, bit for bit.
+    # f32 handles of up to 256 dimensions rerank bucket-major (fp16 filter with measured rounding
+    # bounds + exact fp64 rerank of the survivors); the per-query gather kernel scores every
+    # candidate in fp64.  Same ids, same scores, bit for bit.
     params, X, Q, pick = make_problem(n=20000, nq=300, dim=dim, bucket_overflow=80, table_num=3, permutation_num=2,
                                       n_clusters=12)
     fast = DpfIndex(params, metric=metric)
