@@ -491,3 +491,29 @@ def test_save_and_load_round_trip(tmp_path, dtype, family):
     open(bad, "wb").write(b"garbage!" + blob[8:])
     with pytest.raises(Exception):
         DpfIndex.load(bad)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("family,toi,pb,dns,bb", [("pStable", "original", 3, 32, 28), ("angle", "sampling", 2, 128, 28),
+                                                 ("angle", "continueBitsCount", 3, 64, 30), ("pStable", "original", 0, 32, 28)])
+def test_bucket_major_across_families_and_geometries(family, toi, pb, dns, bb):
+    # the bucket-major path sits behind every hash family / index transform / trie geometry the
+    # probe supports: same answer as the gather path, and as the oracle
+    kw = dict(table_num=3, permutation_num=1) if family == "pStable" else dict(table_num=2, permutation_num=2)
+    params, X, Q, pick = make_problem(n=7000, nq=80, bucket_overflow=40, family=family, type_of_index=toi,
+                                      partition_bits=pb, dir_node_size=dns, bucket_bits=bb, **kw)
+    fast = DpfIndex(params, metric="l2")
+    slow = DpfIndex(dict(params, flags=2), metric="l2")
+    fast.fit(X)
+    slow.fit(X)
+    orc = O.OracleIndex(params)
+    orc.fit(X.astype(np.float64))
+    Q64 = Q.astype(np.float64)
+    for steps in range(0, pb + 1):
+        fi, fs = fast.query_topk(pick, Q, steps=steps, k=10)
+        assert fast.stats()["last_path"] == 1
+        si, ss = slow.query_topk(pick, Q, steps=steps, k=10)
+        assert np.array_equal(fi, si) and np.array_equal(fs, ss, equal_nan=True)
+        off, ids = orc.query_batch(pick, Q64, steps=steps)
+        want = orc.topk(Q64, off, ids, k=10, metric="l2")
+        assert_topk_equal(fi, fs, want[0], want[1])
