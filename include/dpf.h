@@ -50,7 +50,10 @@ enum { DPF_F32 = 0, DPF_F64 = 1 };
 enum { DPF_FLAG_HASH_ONLY = 1,
 /* DPF_FLAG_GATHER_ONLY: always rerank with the per-query gather kernel, never with the
  * bucket-major scan (same results; for measurement and A/B). */
-       DPF_FLAG_GATHER_ONLY = 2 };
+       DPF_FLAG_GATHER_ONLY = 2,
+/* DPF_FLAG_HOST_FOREST: derive the forest on the host (sort-based builder, 16 threads) instead of
+ * on the device (same arrays; for cross-checking and A/B). */
+       DPF_FLAG_HOST_FOREST = 4 };
 
 /* The subset of the reference's Typesafe-Config keys the path consumes
  * (TestSettings.scala:8-45; read at LSH:19-33, Dense:39-58). */
@@ -98,6 +101,9 @@ typedef struct dpf_stats {
     int64_t last_scan_launches;  /* launches of the scan kernel in the last bucket-major batch */
     int64_t snapshot_bytes;      /* HBM bytes of the forest snapshot               */
     int64_t base_bytes;          /* HBM bytes of the resident base rows            */
+    double  fit_ms_hash;         /* last dpf_fit / dpf_load: copy-in + hashing of the new rows      */
+    double  fit_ms_forest;       /* ... forest construction (put / split, RDT:1558-1790) + tiles     */
+    double  fit_ms_total;        /* ... whole call                                                   */
 } dpf_stats;
 
 typedef struct dpf_index dpf_index;
@@ -124,7 +130,9 @@ int dpf_set_sampling_index(dpf_index *ix, const int32_t *sampling_index);
 /* DensevectorRDFInit.newFastFit / newMultiThreadFit (Dense:127-206) after the
  * text has been parsed: appends n rows X[n][dim] (host, element type cfg.dtype);
  * their ids continue the running counter (Dense:181,190).  Hashes are computed
- * on the device; the forest snapshot is rebuilt and uploaded. */
+ * on the device and stay there; the forest snapshot (what put / putInner, RDT:1558-1790,
+ * would have grown by inserting the ids in ascending order) is derived on the device from
+ * the hashes of all ids fitted so far. */
 int dpf_fit(dpf_index *ix, const void *X, int64_t n);
 
 /* LocalitySensitiveHasher.hash for every table (Hasher:44-54 -> LSH:135-166)
@@ -182,6 +190,15 @@ int dpf_get_config(const dpf_index *ix, dpf_config *out);
 int dpf_subindex_distribution(dpf_index *ix, double *out);
 
 int dpf_get_stats(dpf_index *ix, dpf_stats *out);
+
+/* The flattened forest the probe walks, for inspection and cross-checks (what a dump of every
+ * table's partitionRootRec / directory nodes / bucket chains, RDT:940-994, would show):
+ * sizes[4] = element counts of roots[L][P][SEG], dnodes[(num_dnodes + 1)][dirNodeSize] (child word
+ * 0 = empty, (bucket << 1) | 1, directory << 1), leaf_off[num_leaves + 1] and ids[] (bucket
+ * contents, ascending; only this handle's row shard).  dpf_snapshot_copy fills host arrays of
+ * those sizes; a NULL pointer skips that array. */
+int dpf_snapshot_sizes(dpf_index *ix, int64_t *sizes);
+int dpf_snapshot_copy(dpf_index *ix, uint32_t *roots, uint32_t *dnodes, uint32_t *leaf_off, int32_t *ids);
 
 /* Device time of the dominant kernel of the last *_topk* call, measured with HIP
  * events on the stream the kernel ran on, and the bytes that launch has to move by

@@ -35,7 +35,8 @@ class DpfStats(C.Structure):
         (n, C.c_double) for n in ("last_ms_hash", "last_ms_probe", "last_ms_dedupe", "last_ms_rerank",
                                   "last_ms_scan")] + [
         (n, C.c_int64) for n in ("last_path", "last_pairs", "last_forwarded", "last_scan_launches", "snapshot_bytes",
-                                 "base_bytes")]
+                                 "base_bytes")] + [
+        (n, C.c_double) for n in ("fit_ms_hash", "fit_ms_forest", "fit_ms_total")]
 
 
 EXPORTS = (
@@ -43,7 +44,7 @@ EXPORTS = (
     "dpf_set_sampling_index", "dpf_fit", "dpf_hash_batch", "dpf_query_batch", "dpf_free",
     "dpf_query_topk", "dpf_query_topk_device", "dpf_rerank", "dpf_merge_topk_device",
     "dpf_subindex_distribution", "dpf_get_stats", "dpf_last_rerank_profile", "dpf_set_profiling",
-    "dpf_save", "dpf_load", "dpf_get_config",
+    "dpf_save", "dpf_load", "dpf_get_config", "dpf_snapshot_sizes", "dpf_snapshot_copy",
 )
 
 _lib = None
@@ -105,6 +106,10 @@ def lib():
     L.dpf_save.argtypes = [vp, C.c_char_p]
     L.dpf_load.restype = C.c_int
     L.dpf_load.argtypes = [C.c_char_p, C.c_int32, C.POINTER(vp)]
+    L.dpf_snapshot_sizes.restype = C.c_int
+    L.dpf_snapshot_sizes.argtypes = [vp, i64p]
+    L.dpf_snapshot_copy.restype = C.c_int
+    L.dpf_snapshot_copy.argtypes = [vp, vp, vp, vp, vp]
     L.dpf_get_config.restype = C.c_int
     L.dpf_get_config.argtypes = [vp, C.POINTER(DpfConfig)]
     _lib = L
@@ -268,6 +273,18 @@ class DpfIndex:
         out = np.zeros(1 << self.pb, dtype=np.float64)
         self._check(self.L_.dpf_subindex_distribution(self.h, _dp(out)))
         return out
+
+    def snapshot(self):
+        """The flattened forest as host arrays: (roots, dnodes, leaf_off, ids)."""
+        sz = np.zeros(4, dtype=np.int64)
+        self._check(self.L_.dpf_snapshot_sizes(self.h, sz.ctypes.data_as(C.POINTER(C.c_int64))))
+        roots = np.zeros(sz[0], dtype=np.uint32)
+        dnodes = np.zeros(sz[1], dtype=np.uint32)
+        leaf_off = np.zeros(sz[2], dtype=np.uint32)
+        ids = np.zeros(sz[3], dtype=np.int32)
+        self._check(self.L_.dpf_snapshot_copy(self.h, roots.ctypes.data, dnodes.ctypes.data, leaf_off.ctypes.data,
+                                              ids.ctypes.data))
+        return roots, dnodes, leaf_off, ids
 
     def set_profiling(self, on):
         self._check(self.L_.dpf_set_profiling(self.h, 1 if on else 0))

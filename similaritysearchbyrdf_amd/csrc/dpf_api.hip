@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -13,6 +14,7 @@
 
 #include "../../include/dpf.h"
 #include "dpf_device.hpp"
+#include "dpf_build.hpp"
 #include "dpf_forest.hpp"
 
 using namespace dpf;
@@ -35,6 +37,23 @@ struct DevBuf {
         return e;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    void adopt(void *q, size_t bytes) { release(); p = q; cap = bytes; }
+    // grows to `bytes`, keeping the first `keep` bytes
+    hipError_t grow(size_t keep, size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        void *q = nullptr;
+        size_t want = bytes + bytes / 4 + 256;
+        hipError_t e = hipMalloc(&q, want);
+        if (e != hipSuccess) { e = hipMalloc(&q, bytes); want = bytes; }
+        if (e != hipSuccess) return e;
+        if (p && keep > 0) e = hipMemcpy(q, p, keep, hipMemcpyDeviceToDevice);
+        if (e != hipSuccess) { (void)hipFree(q); return e; }
+        release();
+        p = q;
+        cap = want;
+        return hipSuccess;
+    }
     template <typename T> T *as() const { return (T *)p; }
 };
 
@@ -55,7 +74,10 @@ struct dpf_index {
     HashParams hp{};
 
     int64_t n = 0;
-    std::vector<int32_t> h_hashes, h_parts;  // [n][L]
+    DevBuf d_hashes, d_parts;                // hashes / sub-indexes of all n ids, [n][L]
+    std::vector<int32_t> h_hashes, h_parts;  // host mirror of the two, refreshed on demand
+    bool host_hashes_valid = true;
+    std::vector<int64_t> part_counts;        // [L][P] ids per sub-index
     DevBuf d_base;
     int64_t base_rows = 0;                   // resident rows: ids row_begin .. row_begin+base_rows-1
 
@@ -204,7 +226,8 @@ extern "C" void dpf_destroy(dpf_index *ix)
     DevBuf *bufs[] = {&ix->d_fnsT, &ix->d_b, &ix->d_w, &ix->d_chain, &ix->d_part_fns, &ix->d_part_b, &ix->d_part_w,
                       &ix->d_base, &ix->d_roots, &ix->d_dnodes, &ix->d_leaf_off, &ix->d_ids, &ix->ws_qpad,
                       &ix->ws_hashes, &ix->ws_parts, &ix->ws_raw, &ix->ws_bound, &ix->ws_off, &ix->ws_cnt,
-                      &ix->ws_arena, &ix->ws_misc, &ix->ws_hq, &ix->ws_hqids, &ix->ws_hids, &ix->ws_hscores, &ix->ws_stage};
+                      &ix->ws_arena, &ix->ws_misc, &ix->ws_hq, &ix->ws_hqids, &ix->ws_hids, &ix->ws_hscores, &ix->ws_stage,
+                      &ix->d_hashes, &ix->d_parts};
     for (DevBuf *b : bufs) b->release();
     if (ix->d_short_hash) (void)hipFree(ix->d_short_hash);
     if (ix->pinned) (void)hipHostFree(ix->pinned);
@@ -357,6 +380,7 @@ static int upload_snapshot(dpf_index *ix, ForestSnapshot &s)
     ix->st.max_leaf = s.max_leaf;
     ix->st.misflag_events = s.misflag_events;
     ix->st.snapshot_bytes = (int64_t)(s.roots.size() * 4 + s.dnodes.size() * 4 + s.leaf_off.size() * 4 + s.ids.size() * 4);
+    ix->part_counts = s.part_counts;
     if (ix->bucket_major && ix->ks16 > 0 && ix->ntiles > 0 && ix->base_rows > 0) {
         launch_tile_maxnorm((uint4 *)ix->d_tiles.p, ix->nutiles, ix->d_ids.as<int32_t>(), ix->d_base16n.as<float>(), ix->d_base16e.as<float>(),
                             ix->row_begin, ix->row_begin + ix->base_rows, nullptr);
@@ -366,8 +390,71 @@ static int upload_snapshot(dpf_index *ix, ForestSnapshot &s)
 }
 
 
+static int hashes_to_host(dpf_index *ix)
+{
+    if (ix->host_hashes_valid) return DPF_OK;
+    const size_t cnt = (size_t)ix->n * ix->cfg.num_tables;
+    ix->h_hashes.resize(cnt);
+    ix->h_parts.resize(cnt);
+    if (cnt > 0) {
+        HIPCHECK(ix, hipMemcpy(ix->h_hashes.data(), ix->d_hashes.p, cnt * 4, hipMemcpyDeviceToHost));
+        HIPCHECK(ix, hipMemcpy(ix->h_parts.data(), ix->d_parts.p, cnt * 4, hipMemcpyDeviceToHost));
+    }
+    ix->host_hashes_valid = true;
+    return DPF_OK;
+}
+
+// The forest derived on the device from d_hashes / d_parts (dpf_build.hip); same arrays as
+// build_forest + upload_snapshot produce.
+static int device_snapshot(dpf_index *ix, int64_t total)
+{
+    DeviceForest f;
+    std::string err;
+    int rc = build_forest_device(ix->geo, ix->d_hashes.as<int32_t>(), ix->d_parts.as<int32_t>(), total, f, err);
+    if (rc != 0) { f.release(); return fail(ix, rc == -1 ? DPF_ECAPACITY : DPF_EHIP, err); }
+    const int64_t lo = ix->row_begin, hi = std::min<int64_t>(ix->row_end, total);
+    if ((lo > 0 || hi < total) && filter_forest_rows(f, lo, hi, err) != 0) { f.release(); return fail(ix, DPF_EHIP, err); }
+    uint32_t *lt0 = nullptr;
+    uint4 *tiles = nullptr;
+    int64_t ntiles = 0;
+    if (make_forest_tiles(f, 64, &lt0, &tiles, &ntiles, err) != 0) {
+        if (lt0) (void)hipFree(lt0);
+        if (tiles) (void)hipFree(tiles);
+        f.release();
+        return fail(ix, DPF_EHIP, err);
+    }
+    const size_t PS = (size_t)ix->geo.num_parts * ix->geo.seg;
+    ix->d_roots.adopt(f.roots, std::max<size_t>(PS * ix->cfg.num_tables * 4, 16));
+    ix->d_dnodes.adopt(f.dnodes, (size_t)(f.num_dnodes + 1) * ix->geo.dir_node_size * 4);
+    ix->d_leaf_off.adopt(f.leaf_off, ((size_t)f.num_leaves + 1) * 4);
+    ix->d_ids.adopt(f.ids, std::max<size_t>((size_t)f.num_ids * 4, 16));
+    f.roots = f.dnodes = f.leaf_off = nullptr;
+    f.ids = nullptr;
+    ix->d_leaf_tile0.adopt(lt0, ((size_t)f.num_leaves + 1) * 4 + 16);
+    ix->d_tiles.adopt(tiles, std::max<size_t>((size_t)ntiles * 16, 16));
+    ix->nutiles = ix->ntiles = ntiles;
+    ix->num_leaves = f.num_leaves;
+    std::vector<uint32_t> off((size_t)f.num_leaves + 1, 0u);
+    HIPCHECK(ix, hipMemcpy(off.data(), ix->d_leaf_off.p, off.size() * 4, hipMemcpyDeviceToHost));
+    ix->h_leaf_len.resize((size_t)f.num_leaves);
+    for (size_t l = 0; l < ix->h_leaf_len.size(); l++) ix->h_leaf_len[l] = off[l + 1] - off[l];
+    ix->st.num_dnodes = f.num_dnodes;
+    ix->st.num_leaves = f.num_leaves;
+    ix->st.max_leaf = f.max_leaf;
+    ix->st.misflag_events = f.misflag_events;
+    ix->st.snapshot_bytes = (int64_t)(PS * ix->cfg.num_tables * 4 + (size_t)(f.num_dnodes + 1) * ix->geo.dir_node_size * 4 +
+                                      ((size_t)f.num_leaves + 1) * 4 + (size_t)f.num_ids * 4);
+    ix->part_counts = f.part_counts;
+    if (ix->bucket_major && ix->ks16 > 0 && ix->ntiles > 0 && ix->base_rows > 0) {
+        launch_tile_maxnorm((uint4 *)ix->d_tiles.p, ix->nutiles, ix->d_ids.as<int32_t>(), ix->d_base16n.as<float>(), ix->d_base16e.as<float>(),
+                            ix->row_begin, ix->row_begin + ix->base_rows, nullptr);
+        HIPCHECK(ix, hipDeviceSynchronize());
+    }
+    return DPF_OK;
+}
+
 // Second half of a fit, shared with dpf_load: the resident rows are in d_base and the hashes of all
-// `total` ids in h_hashes / h_parts; make the fp16 copy, build the forest and upload it.
+// `total` ids in d_hashes / d_parts; make the fp16 copy and build the forest.
 static int finish_fit(dpf_index *ix, int64_t total, int64_t new_rows)
 {
     int rc;
@@ -386,14 +473,21 @@ static int finish_fit(dpf_index *ix, int64_t total, int64_t new_rows)
     ix->st.num_vectors = total;
     ix->st.base_bytes = (int64_t)((size_t)new_rows * row_bytes);
 
-    ForestSnapshot snap;
-    int hw = (int)std::thread::hardware_concurrency();
-    const char *env = getenv("OMP_NUM_THREADS");
-    int threads = env ? atoi(env) : std::min(hw > 0 ? hw : 8, 16);
-    if (threads < 1) threads = 1;
-    if (build_forest(ix->geo, ix->h_hashes.data(), ix->h_parts.data(), total, threads, snap) != 0)
-        return fail(ix, DPF_ECAPACITY, "dpf_fit: snapshot exceeds 32-bit arena indexing");
-    if ((rc = upload_snapshot(ix, snap)) != DPF_OK) return rc;
+    const auto t0 = std::chrono::steady_clock::now();
+    if (ix->cfg.flags & DPF_FLAG_HOST_FOREST) {
+        if ((rc = hashes_to_host(ix)) != DPF_OK) return rc;
+        ForestSnapshot snap;
+        int hw = (int)std::thread::hardware_concurrency();
+        const char *env = getenv("OMP_NUM_THREADS");
+        int threads = env ? atoi(env) : std::min(hw > 0 ? hw : 8, 16);
+        if (threads < 1) threads = 1;
+        if (build_forest(ix->geo, ix->h_hashes.data(), ix->h_parts.data(), total, threads, snap) != 0)
+            return fail(ix, DPF_ECAPACITY, "dpf_fit: snapshot exceeds 32-bit arena indexing");
+        if ((rc = upload_snapshot(ix, snap)) != DPF_OK) return rc;
+    } else if ((rc = device_snapshot(ix, total)) != DPF_OK) {
+        return rc;
+    }
+    ix->st.fit_ms_forest = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     ix->fitted = total > 0;
     ix->last_valid = false;
     return DPF_OK;
@@ -427,29 +521,32 @@ extern "C" int dpf_fit(dpf_index *ix, const void *X, int64_t n)
             ix->d_base = nb;
         }
     }
-    ix->h_hashes.resize((size_t)total * L);
-    ix->h_parts.resize((size_t)total * L);
+    const auto t0 = std::chrono::steady_clock::now();
+    HIPCHECK(ix, ix->d_hashes.grow((size_t)first * L * 4, std::max<size_t>((size_t)total * L * 4, 16)));
+    HIPCHECK(ix, ix->d_parts.grow((size_t)first * L * 4, std::max<size_t>((size_t)total * L * 4, 16)));
+    if (n > 0) ix->host_hashes_valid = false;
     const int64_t batch = 1 << 17;
     HIPCHECK(ix, ix->ws_stage.ensure((size_t)std::min<int64_t>(batch, std::max<int64_t>(n, 1)) * d * ix->elem));
-    HIPCHECK(ix, ix->ws_hashes.ensure((size_t)std::min<int64_t>(batch, std::max<int64_t>(n, 1)) * L * 4));
-    HIPCHECK(ix, ix->ws_parts.ensure((size_t)std::min<int64_t>(batch, std::max<int64_t>(n, 1)) * L * 4));
     for (int64_t s = 0; s < n; s += batch) {
         const int64_t cnt = std::min(batch, n - s);
         const char *src = (const char *)X + (size_t)s * d * ix->elem;
         HIPCHECK(ix, hipMemcpy(ix->ws_stage.p, src, (size_t)cnt * d * ix->elem, hipMemcpyHostToDevice));
-        launch_hash(c.dtype, ix->ws_stage.p, d, cnt, ix->hp, ix->ws_hashes.as<int32_t>(), ix->ws_parts.as<int32_t>(), nullptr);
-        // rows of this batch that belong to the resident shard
         const int64_t g0 = first + s, g1 = g0 + cnt;
+        launch_hash(c.dtype, ix->ws_stage.p, d, cnt, ix->hp, ix->d_hashes.as<int32_t>() + (size_t)g0 * L,
+                    ix->d_parts.as<int32_t>() + (size_t)g0 * L, nullptr);
+        // rows of this batch that belong to the resident shard
         const int64_t a = std::max(g0, res_begin), bnd = std::min(g1, res_end);
         if (bnd > a) {
             const char *rsrc = (const char *)ix->ws_stage.p + (size_t)(a - g0) * d * ix->elem;
             char *rdst = (char *)ix->d_base.p + (size_t)(a - res_begin) * row_bytes;
             launch_copy_rows(c.dtype, rsrc, bnd - a, d, rdst, ix->dpad, nullptr);
         }
-        HIPCHECK(ix, hipMemcpy(ix->h_hashes.data() + (size_t)g0 * L, ix->ws_hashes.p, (size_t)cnt * L * 4, hipMemcpyDeviceToHost));
-        HIPCHECK(ix, hipMemcpy(ix->h_parts.data() + (size_t)g0 * L, ix->ws_parts.p, (size_t)cnt * L * 4, hipMemcpyDeviceToHost));
+        HIPCHECK(ix, hipDeviceSynchronize());     // the staging buffer is reused by the next batch
     }
-    return finish_fit(ix, total, new_rows);
+    ix->st.fit_ms_hash = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    rc = finish_fit(ix, total, new_rows);
+    ix->st.fit_ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
 }
 
 // ---------------------------------------------------------------------------
@@ -493,6 +590,7 @@ extern "C" int dpf_save(dpf_index *ix, const char *path)
     int rc = check_ready(ix, true);
     if (rc != DPF_OK) return rc;
     HIPCHECK(ix, hipSetDevice(ix->cfg.device));
+    if ((rc = hashes_to_host(ix)) != DPF_OK) return rc;
     FILE *f = fopen(path, "wb");
     if (!f) return fail(ix, DPF_EINVAL, std::string("dpf_save: cannot open ") + path);
     FileW w{f};
@@ -576,10 +674,49 @@ extern "C" int dpf_load(const char *path, int32_t device, dpf_index **out)
     if (e != hipSuccess) return bail(DPF_EHIP, std::string("dpf_load: ") + hipGetErrorString(e));
     if (!r.ok || memcmp(magic, SNAP_MAGIC, 8) != 0) return bail(DPF_EINVAL, "dpf_load: damaged or truncated file");
     fclose(f);
+    e = ix->d_hashes.ensure(std::max<size_t>(hh.size() * 4, 16));
+    if (e == hipSuccess) e = ix->d_parts.ensure(std::max<size_t>(hp.size() * 4, 16));
+    if (e == hipSuccess && !hh.empty()) e = hipMemcpy(ix->d_hashes.p, hh.data(), hh.size() * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess && !hp.empty()) e = hipMemcpy(ix->d_parts.p, hp.data(), hp.size() * 4, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { g_create_error = std::string("dpf_load: ") + hipGetErrorString(e); dpf_destroy(ix); return DPF_EHIP; }
     ix->h_hashes.swap(hh);
     ix->h_parts.swap(hp);
+    ix->host_hashes_valid = true;
     if ((rc = finish_fit(ix, n, base_rows)) != DPF_OK) { g_create_error = "dpf_load: " + ix->err; dpf_destroy(ix); return rc; }
     *out = ix;
+    return DPF_OK;
+}
+
+static void snapshot_sizes(dpf_index *ix, int64_t *sizes)
+{
+    sizes[0] = (int64_t)ix->geo.num_parts * ix->geo.seg * ix->cfg.num_tables;
+    sizes[1] = (ix->st.num_dnodes + 1) * ix->geo.dir_node_size;
+    sizes[2] = ix->st.num_leaves + 1;
+    sizes[3] = 0;
+    for (uint32_t len : ix->h_leaf_len) sizes[3] += len;
+}
+
+extern "C" int dpf_snapshot_sizes(dpf_index *ix, int64_t *sizes)
+{
+    if (!ix || !sizes) return DPF_EINVAL;
+    int rc = check_ready(ix, true);
+    if (rc != DPF_OK) return rc;
+    snapshot_sizes(ix, sizes);
+    return DPF_OK;
+}
+
+extern "C" int dpf_snapshot_copy(dpf_index *ix, uint32_t *roots, uint32_t *dnodes, uint32_t *leaf_off, int32_t *ids)
+{
+    if (!ix) return DPF_EINVAL;
+    int rc = check_ready(ix, true);
+    if (rc != DPF_OK) return rc;
+    int64_t sz[4];
+    snapshot_sizes(ix, sz);
+    HIPCHECK(ix, hipSetDevice(ix->cfg.device));
+    if (roots && sz[0] > 0) HIPCHECK(ix, hipMemcpy(roots, ix->d_roots.p, (size_t)sz[0] * 4, hipMemcpyDeviceToHost));
+    if (dnodes && sz[1] > 0) HIPCHECK(ix, hipMemcpy(dnodes, ix->d_dnodes.p, (size_t)sz[1] * 4, hipMemcpyDeviceToHost));
+    if (leaf_off && sz[2] > 0) HIPCHECK(ix, hipMemcpy(leaf_off, ix->d_leaf_off.p, (size_t)sz[2] * 4, hipMemcpyDeviceToHost));
+    if (ids && sz[3] > 0) HIPCHECK(ix, hipMemcpy(ids, ix->d_ids.p, (size_t)sz[3] * 4, hipMemcpyDeviceToHost));
     return DPF_OK;
 }
 
@@ -588,8 +725,8 @@ extern "C" int dpf_subindex_distribution(dpf_index *ix, double *out)
     if (!ix || !out) return DPF_EINVAL;
     const int P = ix->geo.num_parts, L = ix->cfg.num_tables;
     std::vector<int64_t> cnt((size_t)P, 0);
-    for (int64_t i = 0; i < ix->n; i++)
-        for (int t = 0; t < L; t++) cnt[(size_t)ix->h_parts[(size_t)i * L + t]]++;
+    for (int t = 0; t < L && ix->part_counts.size() == (size_t)L * P; t++)
+        for (int p = 0; p < P; p++) cnt[(size_t)p] += ix->part_counts[(size_t)t * P + p];
     for (int p = 0; p < P; p++) out[p] = (double)cnt[(size_t)p] / (double)L;
     return DPF_OK;
 }

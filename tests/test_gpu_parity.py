@@ -517,3 +517,84 @@ def test_bucket_major_across_families_and_geometries(family, toi, pb, dns, bb):
         off, ids = orc.query_batch(pick, Q64, steps=steps)
         want = orc.topk(Q64, off, ids, k=10, metric="l2")
         assert_topk_equal(fi, fs, want[0], want[1])
+
+
+def _same_snapshot(a, b):
+    for x, y, name in zip(a.snapshot(), b.snapshot(), ("roots", "dnodes", "leaf_off", "ids")):
+        assert x.shape == y.shape, name
+        assert np.array_equal(x, y), name
+    sa, sb = a.stats(), b.stats()
+    for key in ("num_dnodes", "num_leaves", "max_leaf", "misflag_events", "snapshot_bytes"):
+        assert sa[key] == sb[key], key
+    assert np.array_equal(a.subindex_distribution(), b.subindex_distribution())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,B,dns,bb,pb,family", [
+    (2000, 500, 32, 28, 3, "angle"),
+    (3000, 1, 32, 28, 3, "angle"),
+    (3000, 2, 32, 28, 1, "angle"),
+    (3000, 4, 32, 28, 3, "angle"),
+    (6000, 7, 128, 28, 2, "angle"),
+    (6000, 5, 64, 30, 3, "angle"),
+    (6000, 3, 32, 30, 0, "angle"),
+    (5000, 4, 32, 28, 3, "pStable"),
+    (20000, 40, 32, 28, 3, "angle"),
+])
+def test_device_forest_equals_host_forest(n, B, dns, bb, pb, family):
+    # The forest derived on the device (radix-sort rounds over all tables) against the host builder,
+    # which tests/test_forest_builder.py pins to the oracle's one-at-a-time insertion: identical
+    # arrays, so identical walks.  Small overflow thresholds exercise the "born full" corner of
+    # RDT:1719-1768 (a child bucket created with more than BUCKET_OVERFLOW ids).
+    kw = dict(table_num=3, permutation_num=1, pstable_w=2) if family == "pStable" else dict(table_num=2, permutation_num=2)
+    params, X, Q, pick = make_problem(n=n, nq=32, family=family, bucket_overflow=B, dir_node_size=dns, bucket_bits=bb,
+                                      partition_bits=pb, n_clusters=20, **kw)
+    dev = DpfIndex(params, metric="l2")
+    host = DpfIndex(dict(params, flags=4), metric="l2")       # DPF_FLAG_HOST_FOREST
+    dev.fit(X)
+    host.fit(X)
+    _same_snapshot(dev, host)
+    orc = O.OracleIndex(params)
+    orc.fit(X.astype(np.float64))
+    assert dev.stats()["misflag_events"] == orc.misflag_events
+    for steps in (0, pb):
+        assert_same_sets(dev.query_batch(pick, Q, steps=steps), orc.query_batch(pick, Q.astype(np.float64), steps=steps))
+
+
+@pytest.mark.gpu
+def test_device_forest_incremental_fit_and_row_shard():
+    params, X, Q, pick = make_problem(n=9000, nq=32, bucket_overflow=6, n_clusters=10)
+    whole = DpfIndex(dict(params, flags=4), metric="l2")
+    whole.fit(X)
+    parts = DpfIndex(params, metric="l2")
+    parts.fit(X[:2500])
+    parts.fit(X[2500:2501])
+    parts.fit(X[2501:])
+    _same_snapshot(parts, whole)
+    a = DpfIndex(params, metric="l2", row_begin=3000, row_end=7000)
+    b = DpfIndex(dict(params, flags=4), metric="l2", row_begin=3000, row_end=7000)
+    a.fit(X)
+    b.fit(X)
+    _same_snapshot(a, b)
+    ai, asc = a.query_topk(pick, Q, steps=1, k=10)
+    bi, bsc = b.query_topk(pick, Q, steps=1, k=10)
+    assert np.array_equal(ai, bi) and np.array_equal(asc, bsc, equal_nan=True)
+
+
+@pytest.mark.gpu
+def test_device_forest_degenerate_inputs():
+    # all rows equal: one hash per table, every id lands in one level-0 chain of n ids
+    params, X, Q, pick = make_problem(n=1500, nq=8, bucket_overflow=4)
+    X[:] = X[0]
+    dev = DpfIndex(params, metric="l2")
+    host = DpfIndex(dict(params, flags=4), metric="l2")
+    dev.fit(X)
+    host.fit(X)
+    _same_snapshot(dev, host)
+    assert dev.stats()["max_leaf"] == 1500
+    # a single row
+    one = DpfIndex(params, metric="l2")
+    ref = DpfIndex(dict(params, flags=4), metric="l2")
+    one.fit(X[:1])
+    ref.fit(X[:1])
+    _same_snapshot(one, ref)
