@@ -267,7 +267,9 @@ def main():
                                        args.workload, X.shape[1], n, nq, ix.L, ix.pb, params["bucket_overflow"],
                                        steps, k, args.metric),
                        "global_batch": nq, "parallelism": "%s%d" % (sharded.mode, world),
-                       "recall_at_10": recall, "fit_seconds": round(fit_s, 2),
+                       "recall_at_10": recall, "fit_seconds": round(fit_s, 3),
+                       "fit_ms_on_rank0": {"copy_in_and_hash": round(st["fit_ms_hash"], 1),
+                                           "forest_build_on_device": round(st["fit_ms_forest"], 1)},
                        "rerank_path": "bucket-major fp16 scan + exact fp64 rerank" if st["last_path"] == 1 else "gather",
                        "ids_visited_per_query_on_rank0": st["last_raw_candidates"] / nq,
                        "unique_candidates_per_query_on_rank0": (st["last_unique_candidates"] / nq) if st["last_path"] == 0 else None,
