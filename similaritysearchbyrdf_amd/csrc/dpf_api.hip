@@ -89,6 +89,7 @@ struct dpf_index {
     DevBuf d_tiles;                          // {bucket, first id slot, rows, 0} per tile
     DevBuf d_base16e, ws_q16e;               // distances between the rows and their fp16 copies
     DevBuf d_base16n, ws_q16n;               // their squared norms
+    DevBuf ws_qc;                            // per-query record of the scan
     DevBuf d_base16, ws_q16;                 // fp16 copies of the resident rows / of the query batch
     int ks16 = -1;                           // 32-dimension fp16 steps per padded row (-1: no fp16 scan)
     int64_t ntiles = 0, nutiles = 0, num_leaves = 0;
@@ -235,7 +236,7 @@ extern "C" void dpf_destroy(dpf_index *ix)
     for (int i = 0; i < 4; i++) if (ix->ev_scan[i]) (void)hipEventDestroy(ix->ev_scan[i]);
     DevBuf *more[] = {&ix->ws_emit_ucnt, &ix->ws_emit_v, &ix->ws_leaf_units, &ix->ws_unit_off, &ix->ws_q_leaves, &ix->ws_q_leaf_cnt, &ix->d_leaf_tile0, &ix->ws_units, &ix->d_tiles, &ix->ws_lq_cnt, &ix->ws_lq_off, &ix->ws_lq_cursor, &ix->ws_leaf_queries,
                       &ix->ws_seed_cand, &ix->ws_seed_cnt, &ix->ws_seed_ids, &ix->ws_seed_scores, &ix->ws_emit, &ix->ws_emit_cnt,
-                      &ix->d_base16, &ix->ws_q16, &ix->d_base16n, &ix->ws_q16n, &ix->d_base16e, &ix->ws_q16e, &ix->ws_flag, &ix->ws_tau};
+                      &ix->d_base16, &ix->ws_q16, &ix->d_base16n, &ix->ws_q16n, &ix->d_base16e, &ix->ws_q16e, &ix->ws_flag, &ix->ws_tau, &ix->ws_qc};
     for (DevBuf *b : more) b->release();
     delete ix;
 }
@@ -904,9 +905,17 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
         std::sort(srt.begin(), srt.end());
         size_t touched = 0;
         for (auto v : c) touched += v > 0;
-        size_t ttiles = 0;
-        for (size_t l = 0; l < c.size(); l++) if (c[l]) ttiles += (ix->h_leaf_len[l] + 63) / 64;
-        fprintf(stderr, "[dpf] tiles %lld touched %zu units %lld\n", (long long)ix->ntiles, ttiles, (long long)nunits);
+        size_t ttiles = 0, iters = 0, blocks16 = 0;
+        double useful = 0;
+        for (size_t l = 0; l < c.size(); l++) if (c[l]) {
+            const size_t len = ix->h_leaf_len[l], t = (len + 63) / 64, ch = (c[l] + 15) / 16;
+            ttiles += t;
+            iters += t * ch;
+            blocks16 += ((len + 15) / 16) * ch;
+            useful += (double)len * c[l];
+        }
+        fprintf(stderr, "[dpf] tiles %lld touched %zu units %lld; (tile, 16-query chunk) iterations %zu, 16x16 blocks %zu, scores needed %.3g = %.2f of the blocks\n",
+                (long long)ix->ntiles, ttiles, (long long)nunits, iters, blocks16, useful, useful / ((double)blocks16 * 256.0));
         fprintf(stderr, "[dpf] buckets %lld touched %zu pairs %lld queries/bucket: median %u p90 %u p99 %u p999 %u max %u\n",
                 (long long)nl, touched, (long long)pairs, srt[srt.size() / 2], srt[srt.size() * 9 / 10],
                 srt[srt.size() * 99 / 100], srt[srt.size() * 999 / 1000], srt.back());
@@ -930,15 +939,19 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     fill_rerank_params(ix, rp, qpad, k, nullptr, ix->ws_seed_cnt.as<int32_t>(), ix->ws_seed_cand.as<int32_t>(),
                        ix->ws_seed_ids.as<int32_t>(), ix->ws_seed_scores.as<double>());
     rp.cand_stride = SEED_CAP;
-    launch_rerank(ix->cfg.dtype, ix->cfg.metric, rp, nq, stream);
-    launch_tau(ix->cfg.metric, ix->ws_seed_scores.as<double>(), ix->ws_seed_ids.as<int32_t>(), k, nq, ix->ws_tau.as<int32_t>(), stream);
+    static const bool short_lists = !getenv("DPF_NO_SHORT_RERANK");
+    if (short_lists && rerank_short_applies(rp)) launch_rerank_short(ix->cfg.dtype, ix->cfg.metric, rp, nq, stream);
+    else launch_rerank(ix->cfg.dtype, ix->cfg.metric, rp, nq, stream);
 
-    // fp16 copies of the queries, the work list, the scan
+    // fp16 copies of the queries, first thresholds, the work list, the scan
     HIPCHECK(ix, ix->ws_q16.ensure((size_t)nq * ix->ks16 * 32 * 2));
     HIPCHECK(ix, ix->ws_q16n.ensure((size_t)nq * 4));
     HIPCHECK(ix, ix->ws_q16e.ensure((size_t)nq * 4));
+    HIPCHECK(ix, ix->ws_qc.ensure((size_t)nq * 16));
     launch_rows_to_f16((const float *)qpad, ix->dpad, ix->cfg.dim, nq, ix->ws_q16.as<uint16_t>(), ix->ks16 * 32,
                        ix->ws_q16n.as<float>(), ix->ws_q16e.as<float>(), stream);
+    launch_tau(ix->cfg.metric, ix->ws_seed_scores.as<double>(), ix->ws_seed_ids.as<int32_t>(), k, nq, ix->ws_q16n.as<float>(),
+               ix->ws_q16e.as<float>(), d_qids, ix->ks16, ix->ws_tau.as<int32_t>(), (float4 *)ix->ws_qc.p, stream);
     HIPCHECK(ix, ix->ws_units.ensure((size_t)std::max<int64_t>(nunits, 1) * 16));
     launch_units(ix->ws_lq_cnt.as<uint32_t>(), ix->ws_lq_off.as<int64_t>(), ix->d_leaf_tile0.as<uint32_t>(),
                  (const uint4 *)ix->d_tiles.p, nl, ix->ws_unit_off.as<int64_t>(), (uint4 *)ix->ws_units.p, stream);
@@ -954,9 +967,11 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     lp.emit_cnt = ix->ws_emit_cnt.as<int32_t>(); lp.emit_cap = EMIT_CAP;
     lp.debug = getenv("DPF_LS_DEBUG") ? atoi(getenv("DPF_LS_DEBUG")) : 0;
     lp.Q16 = ix->ws_q16.as<uint16_t>(); lp.base16 = ix->d_base16.as<uint16_t>();
-    lp.q16_norm = ix->ws_q16n.as<float>(); lp.base16_norm = ix->d_base16n.as<float>(); lp.q16_err = ix->ws_q16e.as<float>();
+    lp.base16_norm = ix->d_base16n.as<float>(); lp.qc = (const float4 *)ix->ws_qc.p;
     lp.units = (const uint4 *)ix->ws_units.p;
     lp.num_cus = ix->num_cus; lp.ks = ix->ks16;
+    static const int xcds = getenv("DPF_XCDS") ? std::max(1, atoi(getenv("DPF_XCDS"))) : 8;
+    lp.num_xcd = ix->num_cus % xcds == 0 ? xcds : 1;
     // a first slice of the units, then thresholds refined from what it forwarded, then the rest
     static const int first_permille = getenv("DPF_FIRST_PASS") ? atoi(getenv("DPF_FIRST_PASS")) : 100;
     const int64_t n_first = std::min<int64_t>(nunits, nunits * first_permille / 1000);
@@ -966,7 +981,7 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     launch_leafscan(ix->cfg.metric, lp, stream);
     HIPCHECK(ix, hipEventRecord(ix->ev_scan[1], stream));
     if (n_first > 0) {
-        launch_refine(ix->cfg.metric, lp.emit, lp.emit_v, lp.emit_cnt, EMIT_CAP, k, nq, lp.q16_err, lp.tau, stream);
+        launch_refine(ix->cfg.metric, lp.emit, lp.emit_v, lp.emit_cnt, EMIT_CAP, k, nq, ix->ws_q16e.as<float>(), lp.tau, stream);
         ix->scan_launches = 2;
     }
     lp.unit_begin = n_first; lp.unit_end = nunits;
@@ -996,7 +1011,8 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
                        ix->ws_emit.as<int32_t>(), d_ids, d_scores);
     rp.cand_stride = EMIT_CAP;
     HIPCHECK(ix, hipEventRecord(ix->ev[4], stream));
-    launch_rerank(ix->cfg.dtype, ix->cfg.metric, rp, nq, stream);
+    if (short_lists && rerank_short_applies(rp)) launch_rerank_short(ix->cfg.dtype, ix->cfg.metric, rp, nq, stream);
+    else launch_rerank(ix->cfg.dtype, ix->cfg.metric, rp, nq, stream);
     HIPCHECK(ix, hipEventRecord(ix->ev[5], stream));
     HIPCHECK(ix, hipGetLastError());
     ix->last_nq = nq;

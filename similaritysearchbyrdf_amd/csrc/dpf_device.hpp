@@ -72,7 +72,8 @@ struct LeafScanParams {
     int64_t row_begin, row_end;
     const int32_t *qids;
     int32_t exclude_self;
-    int32_t *tau;                // [nq] filter threshold on the score, order-preserving int encoding; tightened in flight
+    int32_t *tau;                // [nq] filter threshold (l2: radius, dot: product), order-preserving int encoding; tightened in flight
+    const float4 *qc;            // [nq] per-query record of the scan, written by k_tau
     int32_t k;
     int32_t *emit;               // [nq][emit_cap] forwarded ids
     float *emit_v;               // [nq][emit_cap] pessimistic score bound of each forwarded row
@@ -81,12 +82,11 @@ struct LeafScanParams {
     int32_t debug;               // ablation switch for measurements (0 in production)
     const uint16_t *Q16;         // fp16 copies: queries [nq][ks*32], rows [rows][ks*32]
     const uint16_t *base16;
-    const float *q16_norm;       // [nq] / [rows] squared norms of the fp16 copies (fp32 sums)
-    const float *base16_norm;
-    const float *q16_err;        // [nq] upper bounds of |q - q~|
+    const float *base16_norm;    // [rows] squared norms of the fp16 copies (fp32 sums)
     const uint4 *units;          // work units of the batch, see k_units
     int64_t unit_begin, unit_end; // the slice of units[] this launch works through
     int32_t num_cus;
+    int32_t num_xcd;             // accelerator dies the workgroups are dealt over (1: plain striding)
     int32_t ks;
 };
 
@@ -123,7 +123,8 @@ void launch_refine(int metric, const int32_t *emit, const float *emit_v, const i
                    const float *q16_err, int32_t *tau, hipStream_t stream);
 void launch_rows_to_f16(const float *src, int64_t src_stride, int dim, int64_t n, uint16_t *dst, int dst_stride,
                          float *norms, float *errs, hipStream_t stream);
-void launch_tau(int metric, const double *seed_scores, const int32_t *seed_ids, int k, int64_t nq, int32_t *tau, hipStream_t stream);
+void launch_tau(int metric, const double *seed_scores, const int32_t *seed_ids, int k, int64_t nq, const float *q16_norm,
+                const float *q16_err, const int32_t *qids, int ks, int32_t *tau, float4 *qc, hipStream_t stream);
 void launch_unique_lists(int32_t *emit, const int32_t *emit_cnt, int32_t cap, int32_t *unique_cnt, int64_t nq, hipStream_t stream);
 void launch_overflow_flag(const int32_t *emit_cnt, int64_t nq, int32_t cap, int32_t *flag, hipStream_t stream);
 void launch_scan_i64(const int64_t *in, int64_t n, int64_t *off, hipStream_t stream);
@@ -132,6 +133,8 @@ void launch_compact(const int32_t *src, const int64_t *src_off, const int32_t *c
                     const int64_t *dst_off, int32_t *dst, int64_t nq, hipStream_t stream);
 void launch_rerank(int dtype, int metric, const RerankParams &p, int64_t nq, hipStream_t stream);
 int rerank_max_chunks16();
+bool rerank_short_applies(const RerankParams &p);
+void launch_rerank_short(int dtype, int metric, const RerankParams &p, int64_t nq, hipStream_t stream);
 void launch_merge_topk(int metric, const int32_t *in_ids, const double *in_scores, int parts,
                        int64_t nq, int k, int32_t *out_ids, double *out_scores, hipStream_t stream);
 void launch_copy_rows(int dtype, const void *src, int64_t n, int dim, void *dst, int64_t dst_stride,

@@ -848,6 +848,125 @@ static void launch_rerank_tm(const RerankParams &p, int64_t nq, hipStream_t stre
 
 int rerank_max_chunks16() { return 1024; }
 
+// Short candidate lists (the seed samples and the forwarded lists of the bucket-major path: a few
+// hundred rows per query): one WAVE per query, 8 lanes per candidate row, UR*8 rows in flight, the
+// next step's ids requested before this step's rows are scored, so a query costs a handful of
+// memory round trips instead of a workgroup's launch, LDS merge and barrier.  The arithmetic
+// reproduces k_rerank's bit for bit for rows of up to 32 16-byte pieces: there lane c of an
+// LPR-lane group sums its piece from zero and the group adds by xor-shuffles LPR/2, ..., 1; here
+// lane gl holds pieces gl, gl + 8, ... as separate partial sums and adds them in the same tree
+// (offsets >= 8 inside the lane, 4, 2, 1 across lanes).
+template <typename T, int METRIC, int NJ, int UR>
+__global__ __launch_bounds__(256) void k_rerank_short(RerankParams p, int64_t nq)
+{
+    typedef typename Vec16<T>::type V;
+    const int lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    const int grp = lane >> 3, gl = lane & 7;
+    const int K = p.k;
+    const int nc = p.chunks16;
+
+    const char *qrow = (const char *)p.Q + (size_t)q * p.q_stride_bytes;
+    V qv[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+        const int c = gl + j * 8;
+        if (c < nc) qv[j] = *(const V *)(qrow + (size_t)c * 16);
+        else { V z = {}; qv[j] = z; }
+    }
+    double ls = worst_score<METRIC>();
+    int32_t lid = 0x7fffffff;
+    double thr_s = ls; int32_t thr_id = lid;
+
+    const int64_t coff = q * p.cand_stride;
+    int32_t cnt = p.cnt[q];
+    if (cnt > p.cand_stride) cnt = (int32_t)p.cand_stride;
+    const int32_t *cand = p.cand + coff;
+    const char *base = (const char *)p.base;
+
+    int32_t idn[UR];
+#pragma unroll
+    for (int u = 0; u < UR; u++) idn[u] = u * 8 + grp < cnt ? cand[u * 8 + grp] : -1;
+    for (int32_t b0 = 0; b0 < cnt; b0 += 8 * UR) {
+        int32_t id[UR];
+        V x[UR][NJ];
+#pragma unroll
+        for (int u = 0; u < UR; u++) {
+            id[u] = idn[u];
+            const bool ok = id[u] >= p.row_begin && id[u] < p.row_end;
+            const char *row = base + (size_t)(ok ? (id[u] - p.row_begin) : 0) * p.base_stride_bytes;
+            if (!ok) id[u] = -1;
+#pragma unroll
+            for (int j = 0; j < NJ; j++) {
+                const int c = gl + j * 8;
+                if (ok && c < nc) x[u][j] = *(const V *)(row + (size_t)c * 16);
+                else { V z = {}; x[u][j] = qv[j]; if (METRIC == 0) x[u][j] = z; }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UR; u++) {
+            const int32_t idx = b0 + 8 * UR + u * 8 + grp;
+            idn[u] = idx < cnt ? cand[idx] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < UR; u++) {
+            double part[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; j++) part[j] = accum16<T, METRIC>(qv[j], x[u][j], 0.0);
+#pragma unroll
+            for (int o = NJ / 2; o > 0; o >>= 1)
+#pragma unroll
+                for (int i = 0; i < o; i++) part[i] += part[i + o];
+            double acc = part[0];
+#pragma unroll
+            for (int o = 4; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+            const bool cand_ok = (gl == 0) && (id[u] >= 0) && better<METRIC>(acc, id[u], thr_s, thr_id);
+            unsigned long long m = __ballot(cand_ok);
+            while (m) {
+                const int src = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const double sc = __shfl(acc, src);
+                const int32_t sid = __shfl(id[u], src);
+                topk_insert<METRIC>(sc, sid, ls, lid, K, lane);
+                thr_s = __shfl(ls, K - 1);
+                thr_id = __shfl(lid, K - 1);
+            }
+        }
+    }
+    if (lane < K) {
+        const bool has = lid != 0x7fffffff;
+        p.out_ids[q * K + lane] = has ? lid : -1;
+        p.out_scores[q * K + lane] = has ? ls : nan("");
+    }
+}
+
+// true when launch_rerank_short serves this row length with k_rerank's exact arithmetic
+bool rerank_short_applies(const RerankParams &p) { return p.chunks16 <= 32 && !p.cand_off && p.cnt; }
+
+template <typename T, int METRIC>
+static void launch_rerank_short_tm(const RerankParams &p, int64_t nq, hipStream_t stream)
+{
+    dim3 grid((unsigned)((nq + 3) / 4)), block(256);
+    const int nc = p.chunks16;
+    if (nc <= 8) hipLaunchKernelGGL((k_rerank_short<T, METRIC, 1, 8>), grid, block, 0, stream, p, nq);
+    else if (nc <= 16) hipLaunchKernelGGL((k_rerank_short<T, METRIC, 2, 8>), grid, block, 0, stream, p, nq);
+    else hipLaunchKernelGGL((k_rerank_short<T, METRIC, 4, 4>), grid, block, 0, stream, p, nq);
+}
+
+void launch_rerank_short(int dtype, int metric, const RerankParams &p, int64_t nq, hipStream_t stream)
+{
+    if (nq <= 0) return;
+    if (dtype == 0) {
+        if (metric == 0) launch_rerank_short_tm<float, 0>(p, nq, stream);
+        else launch_rerank_short_tm<float, 1>(p, nq, stream);
+    } else {
+        if (metric == 0) launch_rerank_short_tm<double, 0>(p, nq, stream);
+        else launch_rerank_short_tm<double, 1>(p, nq, stream);
+    }
+}
+
+
 void launch_rerank(int dtype, int metric, const RerankParams &p, int64_t nq, hipStream_t stream)
 {
     if (nq <= 0) return;
@@ -982,25 +1101,40 @@ void launch_tile_maxnorm(uint4 *tiles, int64_t ntiles, const int32_t *ids, const
     if (ntiles > 0) hipLaunchKernelGGL(k_tile_maxnorm, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, stream, tiles, ntiles, ids, norms, errs, row_begin, row_end);
 }
 
+// Rounding allowance of the filter, per unit of |q~|^2 + |x~|^2: fp32 accumulation of K products on
+// top of the row's share of the threshold (the accumulator starts at -J), the fp32 sums behind the
+// two norms, and the roundings of the threshold arithmetic.
+__device__ __forceinline__ float leafscan_c32(int stride) { return (5.0f * (float)(stride + 8) + 24.0f) * 5.9604645e-8f; }
+
 // The queries of one unit against the tile a wave holds in registers, 16 at a time: thresholds,
-// products on the matrix cores, tests, forwarding.  Shared by the two scan kernels, which differ
-// in how the tile reaches the registers.  s_* are this wave's LDS areas: forwarded (query, id,
-// bound) triples parked until 64 are there; per query slot {G, G2, bits of query index, bits of
-// query id} and {|q~|^2, l2: |q - q~|, dot: the slot's slack}.
+// products on the matrix cores, tests, forwarding.  s_* are this wave's LDS areas: forwarded (query,
+// id, bound) triples parked until 64 are there; per query slot the threshold G, and for the rare
+// paths {trigger level G2, bits of the query index, l2: |q - q~| / dot: the slot's slack, |q~|^2}
+// and the query id.
+//
+// Per query the scan reads one 16-byte record qc = {l2: A = |q~|^2 (1 - c32) / 2, dot: upper bound of
+// |q~|; |q - q~|; |q~|^2; bits of the query id} and its threshold word tau:
+//   l2:  tau holds R >= sqrt(k-th best squared distance) + |q - q~|.  With eta = |q - q~| + |x - x~|,
+//        | |q~ - x~| - |q - x| | <= eta, so a row must be forwarded when |q~ - x~| <= R + |x - x~|max =: hi:
+//        q~.x~ - |x~|^2 (1 - c32) / 2 >= A - hi^2 / 2 =: G.  The accumulator starts at -J(row) =
+//        -|x~|^2 (1 - c32) / 2, so the matrix cores deliver d = q~.x~ - J and the test is d >= G.
+//   dot: tau holds the k-th best product; |q.x - q~.x~| <= |q - q~||x~| + |q||x - x~|, forward when
+//        q~.x~ + that slack >= tau.
+// G2 is the level at which a row is roughly inside 0.985 of the k-th best distance; it only
+// triggers the exact selection below, so it needs no rigour.
 template <int KS, int METRIC, int RB>
 __device__ __forceinline__ void leafscan_chunks(const LeafScanParams &p, const uint16_t *__restrict__ Q16, const f16x8 (&xb)[RB][KS],
                                                 const float (&xn)[RB], const int32_t (&idj)[RB], uint32_t rows, uint32_t nq,
                                                 uint32_t lq0, float xrm, float cxm, int32_t qsc, int32_t qsn, int32_t *s_fq,
-                                                int32_t *s_fid, float *s_fv, float4 *s_slot, float2 *s_slot2, int &nbuf)
+                                                int32_t *s_fid, float *s_fv, float4 *s_slot, float *s_G, int32_t *s_qid, int &nbuf)
 {
+    static_assert(RB == 4, "the tests below are written for 64-row tiles");
     const int lane = threadIdx.x & 63;
     const int i16 = lane & 15, g = lane >> 4;
     const uint32_t jq = 4u * (uint32_t)(i16 & 3) + (uint32_t)(i16 >> 2);   // chunk position of this lane's MFMA row
     constexpr int STRIDE = KS * 32;                       // fp16 elements per padded row
     const unsigned long long lt = (1ull << lane) - 1ull;
-    // fp32 accumulation of the products and of the norms plus the roundings of the threshold
-    // arithmetic below, per unit of |q~|^2 + |x~|^2
-    const float c32 = (3.0f * (float)(STRIDE + 8) + 24.0f) * 5.9604645e-8f;
+    const float c32 = leafscan_c32(STRIDE);
     auto flush = [&](int n) {
         if (lane < n) {
             const int32_t fq = s_fq[lane];
@@ -1011,143 +1145,132 @@ __device__ __forceinline__ void leafscan_chunks(const LeafScanParams &p, const u
             }
         }
     };
-    float J[RB];                                          // the row's share of the threshold
+    float nJ[RB];                                         // minus the row's share of the threshold
 #pragma unroll
     for (int rb = 0; rb < RB; rb++)                       // an absent row never reaches any threshold
-        J[rb] = idj[rb] >= 0 ? (METRIC == 1 ? 0.5f * xn[rb] * (1.0f - c32) : 0.f) : HUGE_VALF;
+        nJ[rb] = idj[rb] >= 0 ? (METRIC == 1 ? -0.5f * xn[rb] * (1.0f - c32) : 0.f) : -HUGE_VALF;
 
     for (uint32_t c = 0; c < nq; c += 16u) {
         f16x8 qa[KS];
         const size_t qat = (size_t)(qsc >= 0 ? qsc : 0);
         {
-            const uint16_t *qrow = Q16 + qat * STRIDE + 8 * g;
+            const uint16_t *qrow = Q16 + ((p.debug & 2) ? (qat & 15) : qat) * STRIDE + 8 * g;   // debug 2: all query rows from one hot spot (timing only)
 #pragma unroll
             for (int t = 0; t < KS; t++) qa[t] = *(const f16x8 *)(qrow + 32 * t);
         }
         const float m_tau = dec_f32(__hip_atomic_load(&p.tau[qat], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        const float m_qn = p.q16_norm[qat], m_qe = p.q16_err[qat];
-        const int32_t m_qid = p.qids ? p.qids[qat] : -1;
+        const float4 qc = p.qc[qat];
         const int32_t qcur = qsc;
         // query indices two chunks ahead
         qsc = qsn;
         qsn = c + 32u + jq < nq ? p.leaf_queries[lq0 + c + 32u + jq] : -1;
 
-        // Per-slot thresholds on d = q~.x~ - J(row); lane i16 of every 16-lane group holds query slot i16.
-        //   l2:  | |q~ - x~| - |q - x| | <= |q - q~| + |x - x~| =: eta, so forward when |q~ - x~|^2 could be
-        //        <= (sqrt(tau) + eta)^2 with the tile's largest |x - x~|:
-        //        q~.x~ - |x~|^2/2 >= (|q~|^2 - (sqrt(tau) + eta)^2) / 2 =: G, rounding taken on the safe side
-        //   dot: |q.x - q~.x~| <= |q - q~||x~| + |q||x - x~|, so forward when q~.x~ + that slack >= tau
-        // G2 is the level at which a row is roughly inside 0.985 sqrt(tau); it only triggers the
-        // exact selection below, so it needs no rigour.
+        // per-slot thresholds; lane i16 of every 16-lane group holds query slot i16
         {
-            float G = HUGE_VALF, G2 = HUGE_VALF, dslack = 0.f;
+            float G = HUGE_VALF, G2 = HUGE_VALF, aux = qc.y;
             if (qcur >= 0) {
-                // v_sqrt_f32 (1 ulp) with the margin folded into the factors below
-                const float qr = __builtin_amdgcn_sqrtf(m_qn) * 1.00001f;   // upper bound of |q~|
                 if (METRIC == 1) {
-                    if (m_tau >= 0.f) {
-                        const float st = __builtin_amdgcn_sqrtf(m_tau) * 1.000001f;
-                        const float hi = st + m_qe + cxm;
-                        G = fmaxf(0.5f * (m_qn * (1.0f - c32) - hi * hi * 1.000001f), -3.0e38f);
-                        const float w = 0.985f * st - m_qe - cxm;
-                        if (w > 0.f) G2 = fmaxf(0.5f * (m_qn * (1.0f + c32) - w * w) + c32 * xrm * xrm, -3.0e38f);
-                    }
+                    const float hi = m_tau + cxm;
+                    G = fmaxf(qc.x - 0.5f * hi * hi * 1.000001f, -3.0e38f);
+                    const float w = 0.985f * m_tau - 1.985f * qc.y - cxm;
+                    if (w > 0.f) G2 = fmaxf(qc.x - 0.5f * w * w, -3.0e38f);
                 } else {
-                    dslack = (m_qe * xrm + (qr + m_qe) * cxm + c32 * qr * xrm) * 1.00001f + 1e-30f;
-                    G = fmaxf(m_tau - dslack, -3.0e38f);
+                    aux = (qc.y * xrm + (qc.x + qc.y) * cxm + c32 * qc.x * xrm) * 1.00001f + 1e-30f;
+                    G = fmaxf(m_tau - aux, -3.0e38f);
                 }
             }
             if (g == 0) {
-                s_slot[i16] = make_float4(G, G2, __int_as_float(qcur), __int_as_float(m_qid));
-                s_slot2[i16] = make_float2(m_qn, METRIC == 1 ? m_qe : dslack);
+                s_G[i16] = G;
+                s_slot[i16] = make_float4(G2, __int_as_float(qcur), aux, qc.z);
+                s_qid[i16] = __float_as_int(qc.w);
             }
         }
         f32x4 acc[RB];
 #pragma unroll
         for (int rb = 0; rb < RB; rb++) {
-            acc[rb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            acc[rb] = (f32x4){nJ[rb], nJ[rb], nJ[rb], nJ[rb]};
             if (rb * 16u >= rows && rb > 0) continue;
 #pragma unroll
             for (int t = 0; t < KS; t++) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qa[t], xb[rb][t], acc[rb], 0, 0, 0);
         }
-        // lane l holds q~(MFMA row 4g + r) . x~(rb*16 + i16) in acc[rb][r]
-        const uint32_t nslot = min(16u, nq - c);       // queries in this chunk
-        if (p.debug) {                                // ablation runs: loads and products only
+        // lane l holds d = q~(MFMA row 4g + r) . x~(rb*16 + i16) - J in acc[rb][r]
+        if (p.debug & 1) {                            // ablation runs: loads and products only
             float t = 0.f;
 #pragma unroll
             for (int rb = 0; rb < RB; rb++) t += acc[rb][rb];
             if (t == 12345.678f) nbuf = 1;
             continue;
         }
+        // the common case first: nothing of this lane's 16 scores reaches its query's threshold
+        {
+            const float4 Gs = *(const float4 *)(s_G + 4 * g);
+            const float e0 = fmaxf(fmaxf(acc[0][0], acc[1][0]), fmaxf(acc[2][0], acc[3][0])) - Gs.x;
+            const float e1 = fmaxf(fmaxf(acc[0][1], acc[1][1]), fmaxf(acc[2][1], acc[3][1])) - Gs.y;
+            const float e2 = fmaxf(fmaxf(acc[0][2], acc[1][2]), fmaxf(acc[2][2], acc[3][2])) - Gs.z;
+            const float e3 = fmaxf(fmaxf(acc[0][3], acc[1][3]), fmaxf(acc[2][3], acc[3][3])) - Gs.w;
+            if (__ballot(fmaxf(fmaxf(e0, e1), fmaxf(e2, e3)) >= 0.f) == 0) continue;
+        }
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            if (4u * r >= nslot) break;
             const int slot = 4 * g + r;
-            const float4 sc = s_slot[slot];
-            float d[RB];
+            const float Gr = s_G[slot];
+            if (__ballot(fmaxf(fmaxf(acc[0][r], acc[1][r]), fmaxf(acc[2][r], acc[3][r])) >= Gr) == 0) continue;
+            const float4 sc = s_slot[slot];           // {G2, query index, |q - q~| or slack, |q~|^2}
+            const int32_t qq = __float_as_int(sc.y), qidq = s_qid[slot];
             bool pass[RB];
             int tight = 0;                            // this lane's rows inside the trigger level
-            unsigned long long many = 0;
 #pragma unroll
             for (int rb = 0; rb < RB; rb++) {
-                d[rb] = acc[rb][r] - J[rb];
-                pass[rb] = d[rb] >= sc.x;
-                if (rb * 16u >= rows && rb > 0) { pass[rb] = false; continue; }
-                many |= __ballot(pass[rb]);
-                if (METRIC == 1) tight += d[rb] >= sc.y ? 1 : 0;
+                pass[rb] = acc[rb][r] >= Gr;
+                if (METRIC == 1) tight += acc[rb][r] >= sc.x ? 1 : 0;
             }
             if (METRIC == 1 && __ballot(tight != 0)) {
                 // rows of the 16-lane group (one query) inside the trigger level
 #pragma unroll
                 for (int o = 1; o < 16; o <<= 1) tight += __shfl_xor(tight, o);
             }
-            if (many) {
-                const int32_t qq = __float_as_int(sc.z), qidq = __float_as_int(sc.w);
-                const float2 s2 = s_slot2[slot];
 #pragma unroll
-                for (int rb = 0; rb < RB; rb++) {
-                    const bool fwd = pass[rb] && !self_excluded(idj[rb], qidq, p.exclude_self);
-                    const unsigned long long m = __ballot(fwd);
-                    if (m) {
-                        if (fwd) {
-                            const int at = nbuf + __popcll(m & lt);
-                            s_fq[at] = qq;
-                            s_fid[at] = idj[rb];
-                            // l2: sqrt(exact distance) <= sqrt(s_hi) + |x - x~|max + |q - q~|, the query's share is
-                            // added by the reader; dot: exact product >= q~.x~ - slack
-                            if (METRIC == 1) {
-                                const float s_hi = fmaf(-2.0f, acc[rb][r], (s2.x + xn[rb]) * (1.0f + c32));
-                                s_fv[at] = sqrtf(fmaxf(s_hi, 0.f)) * 1.000001f + cxm;
-                            } else {
-                                s_fv[at] = acc[rb][r] - s2.y * 1.000001f;
-                            }
+            for (int rb = 0; rb < RB; rb++) {
+                const bool fwd = pass[rb] && !self_excluded(idj[rb], qidq, p.exclude_self);
+                const unsigned long long m = __ballot(fwd);
+                if (m) {
+                    if (fwd) {
+                        const int at = nbuf + __popcll(m & lt);
+                        s_fq[at] = qq;
+                        s_fid[at] = idj[rb];
+                        // l2: |q~ - x~|^2 <= |q~|^2 (1 + c32) + 2 c32 |x~|^2 - 2 d =: s_hi (d = q~.x~ - |x~|^2 (1 - c32) / 2),
+                        // sqrt(exact distance) <= sqrt(s_hi) + |x - x~|max + |q - q~|, the query's share is added by
+                        // the reader; dot: exact product >= q~.x~ - slack
+                        if (METRIC == 1) {
+                            const float s_hi = fmaf(-2.0f, acc[rb][r], sc.w * (1.0f + c32) + 2.0f * c32 * xn[rb]);
+                            s_fv[at] = sqrtf(fmaxf(s_hi, 0.f) * 1.000001f) * 1.000001f + cxm;
+                        } else {
+                            s_fv[at] = acc[rb][r] - sc.z * 1.000001f;
                         }
-                        nbuf += __popcll(m);
-                        if (nbuf >= 64) {
-                            flush(64);
-                            const int rest = nbuf - 64;
-                            int32_t tq2 = 0, ti2 = 0;
-                            float tv2 = 0.f;
-                            if (lane < rest) { tq2 = s_fq[64 + lane]; ti2 = s_fid[64 + lane]; tv2 = s_fv[64 + lane]; }
-                            if (lane < rest) { s_fq[lane] = tq2; s_fid[lane] = ti2; s_fv[lane] = tv2; }
-                            nbuf = rest;
-                        }
+                    }
+                    nbuf += __popcll(m);
+                    if (nbuf >= 64) {
+                        flush(64);
+                        const int rest = nbuf - 64;
+                        int32_t tq2 = 0, ti2 = 0;
+                        float tv2 = 0.f;
+                        if (lane < rest) { tq2 = s_fq[64 + lane]; ti2 = s_fid[64 + lane]; tv2 = s_fv[64 + lane]; }
+                        if (lane < rest) { s_fq[lane] = tq2; s_fid[lane] = ti2; s_fv[lane] = tv2; }
+                        nbuf = rest;
                     }
                 }
             }
             if (METRIC == 1 && tight >= p.k) {
-                // Roughly k or more rows of this tile sit inside 0.985 sqrt(tau).  With
+                // Roughly k or more rows of this tile sit inside 0.985 of the k-th best distance.  With
                 //   v = sqrt(s_hi) + |x - x~|max >= sqrt(exact distance) - |q - q~|
-                // (s_hi = |q~ - x~|^2 rounded up), the k-th smallest v among the RB*16 rows this 16-lane
-                // group holds for the query bounds the query's k-th best distance from above.
-                const int32_t qq = __float_as_int(sc.z), qidq = __float_as_int(sc.w);
-                const float2 s2 = s_slot2[slot];
+                // the k-th smallest v among the RB*16 rows this 16-lane group holds for the query bounds
+                // the query's k-th best distance from above, and R = that + 2 |q - q~| is a new radius.
                 float v[RB];
 #pragma unroll
                 for (int rb = 0; rb < RB; rb++) {
                     const bool ok = idj[rb] >= 0 && !self_excluded(idj[rb], qidq, p.exclude_self);
-                    const float s_hi = fmaf(-2.0f, acc[rb][r], (s2.x + xn[rb]) * (1.0f + c32));
-                    v[rb] = ok ? sqrtf(fmaxf(s_hi, 0.f)) * 1.000001f + cxm : HUGE_VALF;
+                    const float s_hi = fmaf(-2.0f, acc[rb][r], sc.w * (1.0f + c32) + 2.0f * c32 * xn[rb]);
+                    v[rb] = ok ? sqrtf(fmaxf(s_hi, 0.f) * 1.000001f) * 1.000001f + cxm : HUGE_VALF;
                 }
                 int rank[RB];
 #pragma unroll
@@ -1164,10 +1287,8 @@ __device__ __forceinline__ void leafscan_chunks(const LeafScanParams &p, const u
                 }
 #pragma unroll
                 for (int mb = 0; mb < RB; mb++) {
-                    if (rank[mb] == p.k - 1 && v[mb] < HUGE_VALF) {
-                        const float b = (v[mb] + s2.y) * 1.000001f;
-                        atomicMin(&p.tau[qq], enc_f32(b * b * 1.000001f));
-                    }
+                    if (rank[mb] == p.k - 1 && v[mb] < HUGE_VALF)
+                        atomicMin(&p.tau[qq], enc_f32((v[mb] + 2.0f * sc.z) * 1.000002f));
                 }
             }
         }
@@ -1204,11 +1325,19 @@ __global__ __launch_bounds__(256, ls16_waves(KS, RB)) void k_leafscan_f16(LeafSc
     __shared__ int32_t s_fq[4][128], s_fid[4][128];
     __shared__ float s_fv[4][128];
     __shared__ float4 s_slot[4][16];
-    __shared__ float2 s_slot2[4][16];
+    __shared__ __attribute__((aligned(16))) float s_G[4][16];
+    __shared__ int32_t s_qid[4][16];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t W = gridDim.x * 4u, nunits = (uint32_t)p.unit_end;
-    uint32_t u = (uint32_t)p.unit_begin + blockIdx.x * 4u + (uint32_t)wave;
+    // Workgroups go round-robin over the XCDs; each XCD works through its own contiguous share of the
+    // unit list with all its waves side by side, so that at any moment an XCD's L2 serves the queries of
+    // a few hundred neighbouring buckets (which share most of them) instead of the whole batch.
+    const uint32_t nx = (uint32_t)p.num_xcd, xcd = blockIdx.x % nx, slot = blockIdx.x / nx;
+    const uint32_t per = ((uint32_t)((p.unit_end - p.unit_begin + nx - 1) / nx) + 3u) & ~3u;
+    const uint32_t lo = (uint32_t)p.unit_begin + xcd * per;
+    const uint32_t nunits = min((uint32_t)p.unit_end, lo + per);
+    const uint32_t W = (gridDim.x / nx) * 4u;
+    uint32_t u = lo + slot * 4u + (uint32_t)wave;
     if (u >= nunits) return;
     const int i16 = lane & 15, g = lane >> 4;
     // Query j of a 16-query chunk sits in MFMA row 4*(j%4) + j/4, so that the accumulator register
@@ -1263,7 +1392,7 @@ __global__ __launch_bounds__(256, ls16_waves(KS, RB)) void k_leafscan_f16(LeafSc
         U1 = desc(u + 2u * W);
         small(U0, id0, qs0, qs0n);
         leafscan_chunks<KS, METRIC, RB>(p, Q16, xb, xn, idj, rows, nq, lq0, xrm, cxm, qsc, qsn, s_fq[wave], s_fid[wave], s_fv[wave],
-                                        s_slot[wave], s_slot2[wave], nbuf);
+                                        s_slot[wave], s_G[wave], s_qid[wave], nbuf);
     }
     leafscan_flush_rest(p, s_fq[wave], s_fid[wave], s_fv[wave], nbuf);
 }
@@ -1274,7 +1403,9 @@ static void launch_leafscan_f16_m(const LeafScanParams &p, hipStream_t stream)
     const int64_t n = p.unit_end - p.unit_begin;
     if (n <= 0) return;
     const int64_t resident = (int64_t)p.num_cus * ls16_waves(p.ks, RB);   // workgroups the chip holds at once
-    dim3 grid((unsigned)std::min<int64_t>((n + 3) / 4, resident)), block(256);
+    // a multiple of the XCD count, so that every XCD gets the same number of workgroups
+    const int64_t nx = p.num_xcd;
+    dim3 grid((unsigned)(std::min<int64_t>(((n + 3) / 4 + nx - 1) / nx * nx, resident / nx * nx))), block(256);
 #define DPF_LB(KS) hipLaunchKernelGGL((k_leafscan_f16<KS, METRIC, RB>), grid, block, 0, stream, p, p.Q16, p.base16)
     switch (p.ks) {
     case 1: DPF_LB(1); break;
@@ -1325,8 +1456,9 @@ __global__ __launch_bounds__(256) void k_refine(const int32_t *__restrict__ emit
     }
     if (lane == k - 1 && lid >= 0) {
         if (METRIC == 1) {
-            const float b = (ls + q16_err[q]) * 1.000001f;
-            atomicMin(&tau[q], enc_f32(b * b * 1.000001f));
+            // ls >= sqrt(exact distance) - |q - q~| for the k-th best of k distinct rows; the radius
+            // the scan works with is sqrt(k-th best distance) + |q - q~|
+            atomicMin(&tau[q], enc_f32((ls + 2.0f * q16_err[q]) * 1.000002f));
         } else {
             atomicMax(&tau[q], enc_f32(ls));
         }
@@ -1401,29 +1533,36 @@ void launch_rows_to_f16(const float *src, int64_t src_stride, int dim, int64_t n
                        dst, dst_stride, norms, errs);
 }
 
-// First thresholds: the exact k-th best score of each query's seed sample, moved one rounding step
-// to the safe side by the conversion to fp32 (l2: up, dot: down).  A query with fewer than k seeds
-// starts without a threshold.
+// First thresholds and the per-query record the scan reads (see leafscan_chunks).  The exact k-th best
+// score of each query's seed sample, moved to the safe side by the conversion to fp32 (l2: up, dot:
+// down); l2 stores the radius sqrt(k-th best squared distance) + |q - q~|.  A query with fewer than
+// k seeds starts without a threshold.
 template <int METRIC>
 __global__ void k_tau(const double *__restrict__ seed_scores, const int32_t *__restrict__ seed_ids, int k, int64_t nq,
-                      int32_t *__restrict__ tau)
+                      const float *__restrict__ q16_norm, const float *__restrict__ q16_err, const int32_t *__restrict__ qids,
+                      int stride, int32_t *__restrict__ tau, float4 *__restrict__ qc)
 {
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nq) return;
     const int32_t kth_id = seed_ids[q * k + k - 1];
     const double kth = seed_scores[q * k + k - 1];
+    const float qn = q16_norm[q], qe = q16_err[q];
+    const float c32 = leafscan_c32(stride);
     float t;
-    if (METRIC == 1) t = kth_id < 0 ? HUGE_VALF : (float)kth * 1.000001f;
+    if (METRIC == 1) t = kth_id < 0 ? HUGE_VALF : sqrtf(fmaxf((float)kth, 0.f) * 1.000001f) * 1.000001f + qe;
     else t = kth_id < 0 ? -HUGE_VALF : (float)kth - fabsf((float)kth) * 1e-6f - 1e-30f;
     tau[q] = enc_f32(t);
+    qc[q] = make_float4(METRIC == 1 ? 0.5f * qn * (1.0f - c32) : sqrtf(qn) * 1.00001f, qe, qn,
+                        __int_as_float(qids ? qids[q] : -1));
 }
 
-void launch_tau(int metric, const double *seed_scores, const int32_t *seed_ids, int k, int64_t nq, int32_t *tau, hipStream_t stream)
+void launch_tau(int metric, const double *seed_scores, const int32_t *seed_ids, int k, int64_t nq, const float *q16_norm,
+                const float *q16_err, const int32_t *qids, int ks, int32_t *tau, float4 *qc, hipStream_t stream)
 {
     if (nq <= 0) return;
     dim3 grid((unsigned)((nq + 255) / 256)), block(256);
-    if (metric == 0) hipLaunchKernelGGL((k_tau<0>), grid, block, 0, stream, seed_scores, seed_ids, k, nq, tau);
-    else hipLaunchKernelGGL((k_tau<1>), grid, block, 0, stream, seed_scores, seed_ids, k, nq, tau);
+    if (metric == 0) hipLaunchKernelGGL((k_tau<0>), grid, block, 0, stream, seed_scores, seed_ids, k, nq, q16_norm, q16_err, qids, ks * 32, tau, qc);
+    else hipLaunchKernelGGL((k_tau<1>), grid, block, 0, stream, seed_scores, seed_ids, k, nq, q16_norm, q16_err, qids, ks * 32, tau, qc);
 }
 
 void launch_leafscan(int metric, const LeafScanParams &p, hipStream_t stream)
