@@ -89,6 +89,7 @@ struct dpf_index {
     DevBuf d_tiles;                          // {bucket, first id slot, rows, 0} per tile
     DevBuf d_base16e, ws_q16e;               // distances between the rows and their fp16 copies
     DevBuf d_base16n, ws_q16n;               // their squared norms
+    DevBuf d_slot_norm;                      // the rows' squared norms once more, in bucket order beside d_ids
     DevBuf ws_qc;                            // per-query record of the scan
     DevBuf d_base16, ws_q16;                 // fp16 copies of the resident rows / of the query batch
     int ks16 = -1;                           // 32-dimension fp16 steps per padded row (-1: no fp16 scan)
@@ -236,7 +237,7 @@ extern "C" void dpf_destroy(dpf_index *ix)
     for (int i = 0; i < 4; i++) if (ix->ev_scan[i]) (void)hipEventDestroy(ix->ev_scan[i]);
     DevBuf *more[] = {&ix->ws_emit_ucnt, &ix->ws_emit_v, &ix->ws_leaf_units, &ix->ws_unit_off, &ix->ws_q_leaves, &ix->ws_q_leaf_cnt, &ix->d_leaf_tile0, &ix->ws_units, &ix->d_tiles, &ix->ws_lq_cnt, &ix->ws_lq_off, &ix->ws_lq_cursor, &ix->ws_leaf_queries,
                       &ix->ws_seed_cand, &ix->ws_seed_cnt, &ix->ws_seed_ids, &ix->ws_seed_scores, &ix->ws_emit, &ix->ws_emit_cnt,
-                      &ix->d_base16, &ix->ws_q16, &ix->d_base16n, &ix->ws_q16n, &ix->d_base16e, &ix->ws_q16e, &ix->ws_flag, &ix->ws_tau, &ix->ws_qc};
+                      &ix->d_base16, &ix->ws_q16, &ix->d_base16n, &ix->ws_q16n, &ix->d_base16e, &ix->ws_q16e, &ix->ws_flag, &ix->ws_tau, &ix->ws_qc, &ix->d_slot_norm};
     for (DevBuf *b : more) b->release();
     delete ix;
 }
@@ -383,8 +384,9 @@ static int upload_snapshot(dpf_index *ix, ForestSnapshot &s)
     ix->st.snapshot_bytes = (int64_t)(s.roots.size() * 4 + s.dnodes.size() * 4 + s.leaf_off.size() * 4 + s.ids.size() * 4);
     ix->part_counts = s.part_counts;
     if (ix->bucket_major && ix->ks16 > 0 && ix->ntiles > 0 && ix->base_rows > 0) {
+        HIPCHECK(ix, ix->d_slot_norm.ensure(std::max<size_t>(ix->d_ids.cap, 16)));
         launch_tile_maxnorm((uint4 *)ix->d_tiles.p, ix->nutiles, ix->d_ids.as<int32_t>(), ix->d_base16n.as<float>(), ix->d_base16e.as<float>(),
-                            ix->row_begin, ix->row_begin + ix->base_rows, nullptr);
+                            ix->row_begin, ix->row_begin + ix->base_rows, ix->d_slot_norm.as<float>(), nullptr);
         HIPCHECK(ix, hipDeviceSynchronize());
     }
     return DPF_OK;
@@ -447,8 +449,9 @@ static int device_snapshot(dpf_index *ix, int64_t total)
                                       ((size_t)f.num_leaves + 1) * 4 + (size_t)f.num_ids * 4);
     ix->part_counts = f.part_counts;
     if (ix->bucket_major && ix->ks16 > 0 && ix->ntiles > 0 && ix->base_rows > 0) {
+        HIPCHECK(ix, ix->d_slot_norm.ensure(std::max<size_t>(ix->d_ids.cap, 16)));
         launch_tile_maxnorm((uint4 *)ix->d_tiles.p, ix->nutiles, ix->d_ids.as<int32_t>(), ix->d_base16n.as<float>(), ix->d_base16e.as<float>(),
-                            ix->row_begin, ix->row_begin + ix->base_rows, nullptr);
+                            ix->row_begin, ix->row_begin + ix->base_rows, ix->d_slot_norm.as<float>(), nullptr);
         HIPCHECK(ix, hipDeviceSynchronize());
     }
     return DPF_OK;
@@ -916,6 +919,23 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
         }
         fprintf(stderr, "[dpf] tiles %lld touched %zu units %lld; (tile, 16-query chunk) iterations %zu, 16x16 blocks %zu, scores needed %.3g = %.2f of the blocks\n",
                 (long long)ix->ntiles, ttiles, (long long)nunits, iters, blocks16, useful, useful / ((double)blocks16 * 256.0));
+        {   // how evenly the static striding of the scan spreads the work (cost model: 1 per unit + 1 per chunk)
+            const size_t W = (size_t)ix->num_cus * 3 * 4;
+            std::vector<double> load(W, 0.0);
+            size_t u = 0;
+            double total_cost = 0;
+            for (size_t l = 0; l < c.size(); l++) if (c[l]) {
+                const size_t t = (ix->h_leaf_len[l] + 63) / 64;
+                for (size_t ti = 0; ti < t; ti++)
+                    for (uint32_t q0 = 0; q0 < c[l]; q0 += 128, u++) {
+                        const double cost = 1.0 + (double)((std::min<uint32_t>(128u, c[l] - q0) + 15) / 16);
+                        load[u % W] += cost;
+                        total_cost += cost;
+                    }
+            }
+            const double mx = *std::max_element(load.begin(), load.end());
+            fprintf(stderr, "[dpf] static striding over %zu waves: busiest wave %.3f x the mean\n", W, mx / (total_cost / (double)W));
+        }
         fprintf(stderr, "[dpf] buckets %lld touched %zu pairs %lld queries/bucket: median %u p90 %u p99 %u p999 %u max %u\n",
                 (long long)nl, touched, (long long)pairs, srt[srt.size() / 2], srt[srt.size() * 9 / 10],
                 srt[srt.size() * 99 / 100], srt[srt.size() * 999 / 1000], srt.back());
@@ -967,7 +987,7 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     lp.emit_cnt = ix->ws_emit_cnt.as<int32_t>(); lp.emit_cap = EMIT_CAP;
     lp.debug = getenv("DPF_LS_DEBUG") ? atoi(getenv("DPF_LS_DEBUG")) : 0;
     lp.Q16 = ix->ws_q16.as<uint16_t>(); lp.base16 = ix->d_base16.as<uint16_t>();
-    lp.base16_norm = ix->d_base16n.as<float>(); lp.qc = (const float4 *)ix->ws_qc.p;
+    lp.slot_norm = ix->d_slot_norm.as<float>(); lp.qc = (const float4 *)ix->ws_qc.p;
     lp.units = (const uint4 *)ix->ws_units.p;
     lp.num_cus = ix->num_cus; lp.ks = ix->ks16;
     static const int xcds = getenv("DPF_XCDS") ? std::max(1, atoi(getenv("DPF_XCDS"))) : 8;

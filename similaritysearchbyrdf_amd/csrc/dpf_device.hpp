@@ -82,7 +82,7 @@ struct LeafScanParams {
     int32_t debug;               // ablation switch for measurements (0 in production)
     const uint16_t *Q16;         // fp16 copies: queries [nq][ks*32], rows [rows][ks*32]
     const uint16_t *base16;
-    const float *base16_norm;    // [rows] squared norms of the fp16 copies (fp32 sums)
+    const float *slot_norm;      // squared norms of the fp16 copies (fp32 sums), in bucket order beside ids[]
     const uint4 *units;          // work units of the batch, see k_units
     int64_t unit_begin, unit_end; // the slice of units[] this launch works through
     int32_t num_cus;
@@ -117,7 +117,7 @@ void launch_unit_count(const uint32_t *lq_cnt, const uint32_t *leaf_tile0, int64
 void launch_units(const uint32_t *lq_cnt, const int64_t *lq_off, const uint32_t *leaf_tile0, const uint4 *tiles, int64_t nl,
                   const int64_t *unit_off, uint4 *units, hipStream_t stream);
 void launch_tile_maxnorm(uint4 *tiles, int64_t ntiles, const int32_t *ids, const float *norms, const float *errs, int64_t row_begin,
-                         int64_t row_end, hipStream_t stream);
+                         int64_t row_end, float *slot_norms, hipStream_t stream);
 int leafscan_f16_steps(int dim);
 void launch_refine(int metric, const int32_t *emit, const float *emit_v, const int32_t *emit_cnt, int32_t cap, int k, int64_t nq,
                    const float *q16_err, int32_t *tau, hipStream_t stream);

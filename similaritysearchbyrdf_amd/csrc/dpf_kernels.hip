@@ -1066,10 +1066,12 @@ __device__ inline uint32_t ceil16_bits(float f)
 }
 
 // tiles[t].w = two upper bounds over the tile's resident rows, both rounded up to 8 significant bits:
-// the largest norm of the fp16 copies (upper half) and the largest rounding distance (lower half)
+// the largest norm of the fp16 copies (upper half) and the largest rounding distance (lower half).
+// slot_norms[] = the squared norms again, in bucket order beside ids[]: the scan reads a tile's 64
+// norms as one 256-byte run instead of 64 scattered 4-byte reads that each pull a whole line.
 __global__ __launch_bounds__(256) void k_tile_maxnorm(uint4 *__restrict__ tiles, int64_t ntiles, const int32_t *__restrict__ ids,
                                                       const float *__restrict__ norms, const float *__restrict__ errs,
-                                                      int64_t row_begin, int64_t row_end)
+                                                      int64_t row_begin, int64_t row_end, float *__restrict__ slot_norms)
 {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= ntiles) return;
@@ -1077,7 +1079,9 @@ __global__ __launch_bounds__(256) void k_tile_maxnorm(uint4 *__restrict__ tiles,
     float m = 0.f, e = 0.f;
     for (uint32_t i = 0; i < td.z; i++) {
         const int64_t id = ids[td.y + i];
-        if (id >= row_begin && id < row_end) { m = fmaxf(m, norms[id - row_begin]); e = fmaxf(e, errs[id - row_begin]); }
+        float nn = 0.f;
+        if (id >= row_begin && id < row_end) { nn = norms[id - row_begin]; m = fmaxf(m, nn); e = fmaxf(e, errs[id - row_begin]); }
+        slot_norms[td.y + i] = nn;
     }
     td.w = ceil16_bits(sqrtf(m) * 1.00001f) | (ceil16_bits(e) >> 16);
     tiles[t] = td;
@@ -1096,9 +1100,9 @@ void launch_units(const uint32_t *lq_cnt, const int64_t *lq_off, const uint32_t 
     if (nl > 0) hipLaunchKernelGGL(k_units, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, stream, lq_cnt, lq_off, leaf_tile0, tiles, nl, unit_off, units);
 }
 void launch_tile_maxnorm(uint4 *tiles, int64_t ntiles, const int32_t *ids, const float *norms, const float *errs, int64_t row_begin,
-                         int64_t row_end, hipStream_t stream)
+                         int64_t row_end, float *slot_norms, hipStream_t stream)
 {
-    if (ntiles > 0) hipLaunchKernelGGL(k_tile_maxnorm, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, stream, tiles, ntiles, ids, norms, errs, row_begin, row_end);
+    if (ntiles > 0) hipLaunchKernelGGL(k_tile_maxnorm, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, stream, tiles, ntiles, ids, norms, errs, row_begin, row_end, slot_norms);
 }
 
 // Rounding allowance of the filter, per unit of |q~|^2 + |x~|^2: fp32 accumulation of K products on
@@ -1371,6 +1375,7 @@ __global__ __launch_bounds__(256, ls16_waves(KS, RB)) void k_leafscan_f16(LeafSc
         f16x8 xb[RB][KS];
         float xn[RB];                                     // |x~|^2
         const uint32_t rows = U0.y & 0xffu;               // 16-row blocks past the tile's end are skipped throughout
+        const uint32_t tile_slot0 = U0.x;
 #pragma unroll
         for (int rb = 0; rb < RB; rb++) {
             if (rb * 16u >= rows && rb > 0) continue;
@@ -1378,7 +1383,7 @@ __global__ __launch_bounds__(256, ls16_waves(KS, RB)) void k_leafscan_f16(LeafSc
             const uint16_t *row = B16 + at * STRIDE + 8 * g;
 #pragma unroll
             for (int t = 0; t < KS; t++) xb[rb][t] = *(const f16x8 *)(row + 32 * t);
-            xn[rb] = p.base16_norm[at];
+            xn[rb] = rb * 16u + (uint32_t)i16 < rows ? p.slot_norm[tile_slot0 + rb * 16u + (uint32_t)i16] : 0.f;
         }
         int32_t idj[RB];
 #pragma unroll
