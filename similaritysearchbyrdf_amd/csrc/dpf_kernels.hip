@@ -1128,7 +1128,7 @@ __device__ __forceinline__ float leafscan_c32(int stride) { return (5.0f * (floa
 // triggers the exact selection below, so it needs no rigour.
 template <int KS, int METRIC, int RB>
 __device__ __forceinline__ void leafscan_chunks(const LeafScanParams &p, const uint16_t *__restrict__ Q16, const f16x8 (&xb)[RB][KS],
-                                                const float (&xn)[RB], const int32_t (&idj)[RB], uint32_t rows, uint32_t nq,
+                                                const float (&nJ)[RB], const int32_t (&idj)[RB], uint32_t rows, uint32_t nq,
                                                 uint32_t lq0, float xrm, float cxm, int32_t qsc, int32_t qsn, int32_t *s_fq,
                                                 int32_t *s_fid, float *s_fv, float4 *s_slot, float *s_G, int32_t *s_qid, int &nbuf)
 {
@@ -1137,7 +1137,6 @@ __device__ __forceinline__ void leafscan_chunks(const LeafScanParams &p, const u
     const int i16 = lane & 15, g = lane >> 4;
     const uint32_t jq = 4u * (uint32_t)(i16 & 3) + (uint32_t)(i16 >> 2);   // chunk position of this lane's MFMA row
     constexpr int STRIDE = KS * 32;                       // fp16 elements per padded row
-    const unsigned long long lt = (1ull << lane) - 1ull;
     const float c32 = leafscan_c32(STRIDE);
     auto flush = [&](int n) {
         if (lane < n) {
@@ -1149,10 +1148,6 @@ __device__ __forceinline__ void leafscan_chunks(const LeafScanParams &p, const u
             }
         }
     };
-    float nJ[RB];                                         // minus the row's share of the threshold
-#pragma unroll
-    for (int rb = 0; rb < RB; rb++)                       // an absent row never reaches any threshold
-        nJ[rb] = idj[rb] >= 0 ? (METRIC == 1 ? -0.5f * xn[rb] * (1.0f - c32) : 0.f) : -HUGE_VALF;
 
     for (uint32_t c = 0; c < nq; c += 16u) {
         f16x8 qa[KS];
@@ -1221,12 +1216,10 @@ __device__ __forceinline__ void leafscan_chunks(const LeafScanParams &p, const u
             if (__ballot(fmaxf(fmaxf(acc[0][r], acc[1][r]), fmaxf(acc[2][r], acc[3][r])) >= Gr) == 0) continue;
             const float4 sc = s_slot[slot];           // {G2, query index, |q - q~| or slack, |q~|^2}
             const int32_t qq = __float_as_int(sc.y), qidq = s_qid[slot];
-            bool pass[RB];
             int tight = 0;                            // this lane's rows inside the trigger level
+            if (METRIC == 1) {
 #pragma unroll
-            for (int rb = 0; rb < RB; rb++) {
-                pass[rb] = acc[rb][r] >= Gr;
-                if (METRIC == 1) tight += acc[rb][r] >= sc.x ? 1 : 0;
+                for (int rb = 0; rb < RB; rb++) tight += acc[rb][r] >= sc.x ? 1 : 0;
             }
             if (METRIC == 1 && __ballot(tight != 0)) {
                 // rows of the 16-lane group (one query) inside the trigger level
@@ -1235,18 +1228,19 @@ __device__ __forceinline__ void leafscan_chunks(const LeafScanParams &p, const u
             }
 #pragma unroll
             for (int rb = 0; rb < RB; rb++) {
-                const bool fwd = pass[rb] && !self_excluded(idj[rb], qidq, p.exclude_self);
+                const bool fwd = acc[rb][r] >= Gr && !self_excluded(idj[rb], qidq, p.exclude_self);
                 const unsigned long long m = __ballot(fwd);
                 if (m) {
                     if (fwd) {
-                        const int at = nbuf + __popcll(m & lt);
+                        const int at = nbuf + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
                         s_fq[at] = qq;
                         s_fid[at] = idj[rb];
-                        // l2: |q~ - x~|^2 <= |q~|^2 (1 + c32) + 2 c32 |x~|^2 - 2 d =: s_hi (d = q~.x~ - |x~|^2 (1 - c32) / 2),
+                        // l2: |q~ - x~|^2 <= |q~|^2 (1 + c32) + 2 c32 |x~|^2 - 2 d =: s_hi (d = q~.x~ - J, J = |x~|^2 (1 - c32) / 2,
+                        // so 2 c32 |x~|^2 <= 4.001 c32 J),
                         // sqrt(exact distance) <= sqrt(s_hi) + |x - x~|max + |q - q~|, the query's share is added by
                         // the reader; dot: exact product >= q~.x~ - slack
                         if (METRIC == 1) {
-                            const float s_hi = fmaf(-2.0f, acc[rb][r], sc.w * (1.0f + c32) + 2.0f * c32 * xn[rb]);
+                            const float s_hi = fmaf(-2.0f, acc[rb][r], sc.w * (1.0f + c32) - 4.001f * c32 * nJ[rb]);
                             s_fv[at] = sqrtf(fmaxf(s_hi, 0.f) * 1.000001f) * 1.000001f + cxm;
                         } else {
                             s_fv[at] = acc[rb][r] - sc.z * 1.000001f;
@@ -1273,26 +1267,26 @@ __device__ __forceinline__ void leafscan_chunks(const LeafScanParams &p, const u
 #pragma unroll
                 for (int rb = 0; rb < RB; rb++) {
                     const bool ok = idj[rb] >= 0 && !self_excluded(idj[rb], qidq, p.exclude_self);
-                    const float s_hi = fmaf(-2.0f, acc[rb][r], sc.w * (1.0f + c32) + 2.0f * c32 * xn[rb]);
+                    const float s_hi = fmaf(-2.0f, acc[rb][r], sc.w * (1.0f + c32) - 4.001f * c32 * nJ[rb]);
                     v[rb] = ok ? sqrtf(fmaxf(s_hi, 0.f) * 1.000001f) * 1.000001f + cxm : HUGE_VALF;
                 }
-                int rank[RB];
-#pragma unroll
-                for (int mb = 0; mb < RB; mb++) rank[mb] = 0;
-                for (int j = 0; j < 16; j++) {
-                    const int src = 16 * g + j;
-#pragma unroll
-                    for (int ob = 0; ob < RB; ob++) {
-                        const float o = __shfl(v[ob], src);
-#pragma unroll
-                        for (int mb = 0; mb < RB; mb++)
-                            rank[mb] += (o < v[mb] || (o == v[mb] && (j < i16 || (j == i16 && ob < mb)))) ? 1 : 0;
-                    }
-                }
-#pragma unroll
+                // rank of each of this lane's RB values among the group's 16*RB, one value at a time: the path
+                // is rare, and keeping four ranks at once costs registers the whole kernel would pay for
+#pragma nounroll
                 for (int mb = 0; mb < RB; mb++) {
-                    if (rank[mb] == p.k - 1 && v[mb] < HUGE_VALF)
-                        atomicMin(&p.tau[qq], enc_f32((v[mb] + 2.0f * sc.z) * 1.000002f));
+                    const float mine = mb == 0 ? v[0] : mb == 1 ? v[1] : mb == 2 ? v[2] : v[3];
+                    int rank = 0;
+#pragma nounroll
+                    for (int j = 0; j < 16; j++) {
+                        const int src = 16 * g + j;
+#pragma unroll
+                        for (int ob = 0; ob < RB; ob++) {
+                            const float o = __shfl(v[ob], src);
+                            rank += (o < mine || (o == mine && (j < i16 || (j == i16 && ob < mb)))) ? 1 : 0;
+                        }
+                    }
+                    if (rank == p.k - 1 && mine < HUGE_VALF)
+                        atomicMin(&p.tau[qq], enc_f32((mine + 2.0f * sc.z) * 1.000002f));
                 }
             }
         }
@@ -1353,7 +1347,7 @@ __global__ __launch_bounds__(256, ls16_waves(KS, RB)) void k_leafscan_f16(LeafSc
 
     int nbuf = 0;
     auto desc = [&](uint32_t uu) { return uu < nunits ? p.units[uu] : make_uint4(0u, 0u, 0u, 0u); };
-    auto small = [&](const uint4 &U, int32_t (&id)[RB], int32_t &qs, int32_t &qsn) {
+    auto small = [&](const uint4 &U, int32_t (&id)[RB], int32_t &qs) {
         const uint32_t rows = U.y & 0xffu, nq = U.y >> 8;
 #pragma unroll
         for (int rb = 0; rb < RB; rb++) {
@@ -1363,17 +1357,17 @@ __global__ __launch_bounds__(256, ls16_waves(KS, RB)) void k_leafscan_f16(LeafSc
             id[rb] = v;
         }
         qs = jq < nq ? p.leaf_queries[U.z + jq] : -1;
-        qsn = 16u + jq < nq ? p.leaf_queries[U.z + 16u + jq] : -1;
     };
 
     uint4 U0 = desc(u), U1 = desc(u + W);
-    int32_t id0[RB], qs0, qs0n;
-    small(U0, id0, qs0, qs0n);
+    int32_t id0[RB], qs0;
+    small(U0, id0, qs0);
 
     for (; u < nunits; u += W) {
         // this unit's rows
         f16x8 xb[RB][KS];
-        float xn[RB];                                     // |x~|^2
+        float nJ[RB];                                     // minus the row's share of the threshold, -|x~|^2 (1 - c32) / 2;
+                                                          // -inf for an absent row, which then never reaches any threshold
         const uint32_t rows = U0.y & 0xffu;               // 16-row blocks past the tile's end are skipped throughout
         const uint32_t tile_slot0 = U0.x;
 #pragma unroll
@@ -1383,20 +1377,25 @@ __global__ __launch_bounds__(256, ls16_waves(KS, RB)) void k_leafscan_f16(LeafSc
             const uint16_t *row = B16 + at * STRIDE + 8 * g;
 #pragma unroll
             for (int t = 0; t < KS; t++) xb[rb][t] = *(const f16x8 *)(row + 32 * t);
-            xn[rb] = rb * 16u + (uint32_t)i16 < rows ? p.slot_norm[tile_slot0 + rb * 16u + (uint32_t)i16] : 0.f;
+            nJ[rb] = rb * 16u + (uint32_t)i16 < rows ? p.slot_norm[tile_slot0 + rb * 16u + (uint32_t)i16] : 0.f;
         }
         int32_t idj[RB];
 #pragma unroll
-        for (int rb = 0; rb < RB; rb++) idj[rb] = id0[rb];
+        for (int rb = 0; rb < RB; rb++) {
+            idj[rb] = id0[rb];
+            const bool there = id0[rb] >= 0 && (rb == 0 || rb * 16u < rows);
+            nJ[rb] = there ? (METRIC == 1 ? -0.5f * nJ[rb] * (1.0f - leafscan_c32(STRIDE)) : 0.f) : -HUGE_VALF;
+        }
         const uint32_t nq = U0.y >> 8, lq0 = U0.z;
         const float xrm = __uint_as_float(U0.w & 0xffff0000u);    // upper bound of the largest |x~| of the tile
         const float cxm = __uint_as_float(U0.w << 16);            // upper bound of the largest |x - x~|
         // the next unit's ids and first query indices, the descriptor after it
-        const int32_t qsc = qs0, qsn = qs0n;
+        // the second chunk's query indices ride along with the rows
+        const int32_t qsc = qs0, qsn = 16u + jq < nq ? p.leaf_queries[lq0 + 16u + jq] : -1;
         U0 = U1;
         U1 = desc(u + 2u * W);
-        small(U0, id0, qs0, qs0n);
-        leafscan_chunks<KS, METRIC, RB>(p, Q16, xb, xn, idj, rows, nq, lq0, xrm, cxm, qsc, qsn, s_fq[wave], s_fid[wave], s_fv[wave],
+        small(U0, id0, qs0);
+        leafscan_chunks<KS, METRIC, RB>(p, Q16, xb, nJ, idj, rows, nq, lq0, xrm, cxm, qsc, qsn, s_fq[wave], s_fid[wave], s_fv[wave],
                                         s_slot[wave], s_G[wave], s_qid[wave], nbuf);
     }
     leafscan_flush_rest(p, s_fq[wave], s_fid[wave], s_fv[wave], nbuf);
