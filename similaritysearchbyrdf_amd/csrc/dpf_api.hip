@@ -1291,15 +1291,16 @@ extern "C" int dpf_last_rerank_profile(dpf_index *ix, double *ms, int64_t *algor
     if (ms) *ms = t;
     const int64_t row = (int64_t)ix->cfg.dim * (int64_t)ix->elem;
     if (ix->last_path == 1) {
-        // bucket-major scan: every touched bucket's rows and ids once, one query row + threshold +
-        // ids per (query, bucket) incidence, one (query, id) pair per forwarded candidate
+        // bucket-major scan: every touched bucket's rows with their ids and norms once; one query row,
+        // its index, threshold and 16-byte record per (query, bucket) incidence; one (id, bound) pair
+        // per forwarded candidate
         std::vector<uint32_t> c((size_t)ix->num_leaves);
         HIPCHECK(ix, hipMemcpy(c.data(), ix->ws_lq_cnt.p, c.size() * 4, hipMemcpyDeviceToHost));
         int64_t touched_rows = 0;
         for (size_t l = 0; l < c.size(); l++)
             if (c[l]) touched_rows += ix->h_leaf_len[l];
         const int64_t srow = (int64_t)ix->ks16 * 64;
-        if (algorithmic_bytes) *algorithmic_bytes = touched_rows * (srow + 4) + ix->st.last_pairs * (srow + 12) + uniq * 8;
+        if (algorithmic_bytes) *algorithmic_bytes = touched_rows * (srow + 8) + ix->st.last_pairs * (srow + 24) + uniq * 8;
         return DPF_OK;
     }
     // gather rerank: candidate rows + candidate ids + query rows + (score, id) results
