@@ -104,6 +104,8 @@ typedef struct dpf_stats {
     double  fit_ms_hash;         /* last dpf_fit / dpf_load: copy-in + hashing of the new rows      */
     double  fit_ms_forest;       /* ... forest construction (put / split, RDT:1558-1790) + tiles     */
     double  fit_ms_total;        /* ... whole call                                                   */
+    int64_t last_overflowed;     /* queries of the last bucket-major batch whose forward list overflowed and
+                                    that were answered by the gather path instead */
 } dpf_stats;
 
 typedef struct dpf_index dpf_index;

@@ -91,6 +91,8 @@ struct dpf_index {
     DevBuf d_base16n, ws_q16n;               // their squared norms
     DevBuf d_slot_norm;                      // the rows' squared norms once more, in bucket order beside d_ids
     DevBuf ws_qc;                            // per-query record of the scan
+    DevBuf ws_ovf;                           // queries whose forward list overflowed
+    DevBuf sub_q, sub_qids, sub_ids, sub_scores, sub_ws[6];   // their batch on the gather path
     DevBuf d_base16, ws_q16;                 // fp16 copies of the resident rows / of the query batch
     int ks16 = -1;                           // 32-dimension fp16 steps per padded row (-1: no fp16 scan)
     int64_t ntiles = 0, nutiles = 0, num_leaves = 0;
@@ -237,7 +239,8 @@ extern "C" void dpf_destroy(dpf_index *ix)
     for (int i = 0; i < 4; i++) if (ix->ev_scan[i]) (void)hipEventDestroy(ix->ev_scan[i]);
     DevBuf *more[] = {&ix->ws_emit_ucnt, &ix->ws_emit_v, &ix->ws_leaf_units, &ix->ws_unit_off, &ix->ws_q_leaves, &ix->ws_q_leaf_cnt, &ix->d_leaf_tile0, &ix->ws_units, &ix->d_tiles, &ix->ws_lq_cnt, &ix->ws_lq_off, &ix->ws_lq_cursor, &ix->ws_leaf_queries,
                       &ix->ws_seed_cand, &ix->ws_seed_cnt, &ix->ws_seed_ids, &ix->ws_seed_scores, &ix->ws_emit, &ix->ws_emit_cnt,
-                      &ix->d_base16, &ix->ws_q16, &ix->d_base16n, &ix->ws_q16n, &ix->d_base16e, &ix->ws_q16e, &ix->ws_flag, &ix->ws_tau, &ix->ws_qc, &ix->d_slot_norm};
+                      &ix->d_base16, &ix->ws_q16, &ix->d_base16n, &ix->ws_q16n, &ix->d_base16e, &ix->ws_q16e, &ix->ws_flag, &ix->ws_tau, &ix->ws_qc, &ix->d_slot_norm, &ix->ws_ovf, &ix->sub_q, &ix->sub_qids, &ix->sub_ids,
+                      &ix->sub_scores, &ix->sub_ws[0], &ix->sub_ws[1], &ix->sub_ws[2], &ix->sub_ws[3], &ix->sub_ws[4], &ix->sub_ws[5]};
     for (DevBuf *b : more) b->release();
     delete ix;
 }
@@ -990,7 +993,7 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     lp.slot_norm = ix->d_slot_norm.as<float>(); lp.qc = (const float4 *)ix->ws_qc.p;
     lp.units = (const uint4 *)ix->ws_units.p;
     lp.num_cus = ix->num_cus; lp.ks = ix->ks16;
-    static const int xcds = getenv("DPF_XCDS") ? std::max(1, atoi(getenv("DPF_XCDS"))) : 8;
+    static const int xcds = getenv("DPF_XCDS") ? std::max(1, atoi(getenv("DPF_XCDS"))) : 1;
     lp.num_xcd = ix->num_cus % xcds == 0 ? xcds : 1;
     // a first slice of the units, then thresholds refined from what it forwarded, then the rest
     static const int first_permille = getenv("DPF_FIRST_PASS") ? atoi(getenv("DPF_FIRST_PASS")) : 100;
@@ -1008,7 +1011,8 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     HIPCHECK(ix, hipEventRecord(ix->ev_scan[2], stream));
     launch_leafscan(ix->cfg.metric, lp, stream);
     HIPCHECK(ix, hipEventRecord(ix->ev_scan[3], stream));
-    launch_overflow_flag(ix->ws_emit_cnt.as<int32_t>(), nq, EMIT_CAP, ix->ws_flag.as<int32_t>(), stream);
+    HIPCHECK(ix, ix->ws_ovf.ensure((size_t)nq * 4));
+    launch_overflow_list(ix->ws_emit_cnt.as<int32_t>(), nq, EMIT_CAP, ix->ws_flag.as<int32_t>(), ix->ws_ovf.as<int32_t>(), stream);
     HIPCHECK(ix, hipMemcpyAsync(ix->pinned + 1, ix->ws_flag.p, 4, hipMemcpyDeviceToHost, stream));
     HIPCHECK(ix, hipStreamSynchronize(stream));
     ix->st.last_pairs = pairs;
@@ -1019,7 +1023,11 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
         fprintf(stderr, "[dpf] forwarded per query: median %d p90 %d p99 %d max %d (cap %d)\n", c[c.size() / 2],
                 c[c.size() * 9 / 10], c[c.size() * 99 / 100], c.back(), EMIT_CAP);
     }
-    if ((int32_t)(ix->pinned[1] & 0xffffffff) != 0) return DPF_OK;     // overflow: gather path decides
+    // Queries whose forward list overflowed are answered by the gather path afterwards, as a batch of
+    // their own; when they are many the whole batch goes that way.
+    const int64_t n_ovf = (int32_t)(ix->pinned[1] & 0xffffffff);
+    ix->st.last_overflowed = n_ovf;
+    if (n_ovf * 8 > nq) return DPF_OK;
 
     // distinct ids of every forward list (a row is forwarded once per tree it was found in)
     const bool dedupe = 2 * (size_t)EMIT_CAP * 4 <= 128 * 1024;       // the table of the longest possible list fits LDS
@@ -1035,6 +1043,33 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     else launch_rerank(ix->cfg.dtype, ix->cfg.metric, rp, nq, stream);
     HIPCHECK(ix, hipEventRecord(ix->ev[5], stream));
     HIPCHECK(ix, hipGetLastError());
+    if (n_ovf > 0) {
+        const int64_t row_bytes = ix->dpad * (int64_t)ix->elem;
+        HIPCHECK(ix, ix->sub_q.ensure((size_t)n_ovf * row_bytes));
+        HIPCHECK(ix, ix->sub_qids.ensure((size_t)n_ovf * 4));
+        HIPCHECK(ix, ix->sub_ids.ensure((size_t)n_ovf * k * 4));
+        HIPCHECK(ix, ix->sub_scores.ensure((size_t)n_ovf * k * 8));
+        launch_gather_queries(ix->ws_ovf.as<int32_t>(), n_ovf, qpad, row_bytes, d_qids, ix->sub_q.p, ix->sub_qids.as<int32_t>(), stream);
+        // the gather path works in the per-batch buffers whose contents the statistics of this batch read
+        DevBuf *mine[] = {&ix->ws_hashes, &ix->ws_parts, &ix->ws_raw, &ix->ws_bound, &ix->ws_off, &ix->ws_cnt};
+        for (int i = 0; i < 6; i++) std::swap(*mine[i], ix->sub_ws[i]);
+        const bool prof = ix->profiling;
+        ix->profiling = false;
+        int rc = run_probe(ix, d_qids ? ix->sub_qids.as<int32_t>() : nullptr, ix->sub_q.p, qstride, n_ovf, steps, stream);
+        if (rc == DPF_OK) {
+            RerankParams sp;
+            fill_rerank_params(ix, sp, ix->sub_q.p, k, ix->ws_off.as<int64_t>(), ix->ws_cnt.as<int32_t>(), ix->ws_arena.as<int32_t>(),
+                               ix->sub_ids.as<int32_t>(), ix->sub_scores.as<double>());
+            launch_rerank(ix->cfg.dtype, ix->cfg.metric, sp, n_ovf, stream);
+            launch_scatter_results(ix->ws_ovf.as<int32_t>(), n_ovf, k, ix->sub_ids.as<int32_t>(), ix->sub_scores.as<double>(), d_ids,
+                                   d_scores, stream);
+        }
+        ix->profiling = prof;
+        for (int i = 0; i < 6; i++) std::swap(*mine[i], ix->sub_ws[i]);
+        if (rc != DPF_OK) return rc;
+        HIPCHECK(ix, hipGetLastError());
+    }
+    ix->st.last_overflowed = n_ovf;
     ix->last_nq = nq;
     ix->last_valid = true;
     ix->last_path = 1;

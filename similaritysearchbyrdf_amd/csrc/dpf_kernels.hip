@@ -1258,7 +1258,7 @@ __device__ __forceinline__ void leafscan_chunks(const LeafScanParams &p, const u
                     }
                 }
             }
-            if (METRIC == 1 && tight >= p.k) {
+            if (METRIC == 1 && tight >= p.k && !(p.debug & 4)) {
                 // Roughly k or more rows of this tile sit inside 0.985 of the k-th best distance.  With
                 //   v = sqrt(s_hi) + |x - x~|max >= sqrt(exact distance) - |q - q~|
                 // the k-th smallest v among the RB*16 rows this 16-lane group holds for the query bounds
@@ -1575,16 +1575,55 @@ void launch_leafscan(int metric, const LeafScanParams &p, hipStream_t stream)
     else launch_leafscan_f16_m<1, 4>(p, stream);
 }
 
-__global__ void k_overflow_flag(const int32_t *__restrict__ emit_cnt, int64_t nq, int32_t cap, int32_t *flag)
+// flag[0] = number of queries whose forward list overflowed, their indices in list[]
+__global__ void k_overflow_list(const int32_t *__restrict__ emit_cnt, int64_t nq, int32_t cap, int32_t *flag, int32_t *__restrict__ list)
 {
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q < nq && emit_cnt[q] > cap) atomicOr(flag, 1);
+    if (q < nq && emit_cnt[q] > cap) list[atomicAdd(flag, 1)] = (int32_t)q;
 }
 
-void launch_overflow_flag(const int32_t *emit_cnt, int64_t nq, int32_t cap, int32_t *flag, hipStream_t stream)
+void launch_overflow_list(const int32_t *emit_cnt, int64_t nq, int32_t cap, int32_t *flag, int32_t *list, hipStream_t stream)
 {
     if (nq <= 0) return;
-    hipLaunchKernelGGL(k_overflow_flag, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, stream, emit_cnt, nq, cap, flag);
+    hipLaunchKernelGGL(k_overflow_list, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, stream, emit_cnt, nq, cap, flag, list);
+}
+
+// The queries named in list[] copied out as a batch of their own (16-byte pieces of the padded rows,
+// and the query ids when there are any) ...
+__global__ void k_gather_queries(const int32_t *__restrict__ list, int64_t n, const uint4 *__restrict__ Q, int64_t pieces,
+                                 const int32_t *__restrict__ qids, uint4 *__restrict__ subQ, int32_t *__restrict__ sub_qids)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * pieces) return;
+    const int64_t r = i / pieces, c = i - r * pieces;
+    const int64_t q = list[r];
+    subQ[i] = Q[q * pieces + c];
+    if (c == 0 && qids) sub_qids[r] = qids[q];
+}
+// ... and their results put back in place
+__global__ void k_scatter_results(const int32_t *__restrict__ list, int64_t n, int k, const int32_t *__restrict__ sub_ids,
+                                  const double *__restrict__ sub_scores, int32_t *__restrict__ ids, double *__restrict__ scores)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * k) return;
+    const int64_t r = i / k, e = i - r * k;
+    const int64_t q = list[r];
+    ids[q * k + e] = sub_ids[i];
+    scores[q * k + e] = sub_scores[i];
+}
+void launch_gather_queries(const int32_t *list, int64_t n, const void *Q, int64_t row_bytes, const int32_t *qids, void *subQ,
+                           int32_t *sub_qids, hipStream_t stream)
+{
+    const int64_t total = n * (row_bytes / 16);
+    if (total > 0) hipLaunchKernelGGL(k_gather_queries, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, list, n, (const uint4 *)Q,
+                                      row_bytes / 16, qids, (uint4 *)subQ, sub_qids);
+}
+void launch_scatter_results(const int32_t *list, int64_t n, int k, const int32_t *sub_ids, const double *sub_scores, int32_t *ids,
+                            double *scores, hipStream_t stream)
+{
+    const int64_t total = n * k;
+    if (total > 0) hipLaunchKernelGGL(k_scatter_results, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, list, n, k, sub_ids,
+                                      sub_scores, ids, scores);
 }
 
 // k_unique_lists: the scan forwards a row once per tree it was found in (near neighbours sit in

@@ -598,3 +598,31 @@ def test_device_forest_degenerate_inputs():
     one.fit(X[:1])
     ref.fit(X[:1])
     _same_snapshot(one, ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("metric,with_qids", [("l2", True), ("l2", False), ("dot", True)])
+def test_overflowed_queries_take_the_gather_path_alone(monkeypatch, metric, with_qids):
+    # a forward-list cap that only a few queries exceed: those are answered by the gather path as a
+    # batch of their own, the others by the scan, and the batch equals the gather-only handle's
+    params, X, Q, pick = make_problem(n=12000, nq=400, bucket_overflow=60, n_clusters=8)
+    slow = DpfIndex(dict(params, flags=2), metric=metric)
+    slow.fit(X)
+    qids = pick if with_qids else None
+    want = slow.query_topk(qids, Q, steps=1, k=10)
+    seen_partial = False
+    for cap in (512, 256, 128, 96, 64, 48, 32, 24, 16):
+        monkeypatch.setenv("DPF_EMIT_CAP", str(cap))
+        fast = DpfIndex(params, metric=metric)
+        fast.fit(X)
+        got = fast.query_topk(qids, Q, steps=1, k=10)
+        st = fast.stats()
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1], equal_nan=True), cap
+        if st["last_path"] == 1 and st["last_overflowed"] > 0:
+            seen_partial = True
+            # and once more on the same handle: the per-batch buffers are back in place
+            again = fast.query_topk(qids, Q, steps=1, k=10)
+            assert np.array_equal(again[0], want[0]) and np.array_equal(again[1], want[1], equal_nan=True)
+            assert fast.stats()["last_raw_candidates"] == st["last_raw_candidates"]
+        fast.close()
+    assert seen_partial
