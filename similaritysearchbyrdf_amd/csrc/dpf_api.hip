@@ -92,6 +92,7 @@ struct dpf_index {
     DevBuf d_slot_norm;                      // the rows' squared norms once more, in bucket order beside d_ids
     DevBuf ws_qc;                            // per-query record of the scan
     DevBuf ws_ovf;                           // queries whose forward list overflowed
+    int32_t emit_cap = 8192;                 // entries per forward list
     DevBuf sub_q, sub_qids, sub_ids, sub_scores, sub_ws[6];   // their batch on the gather path
     DevBuf d_base16, ws_q16;                 // fp16 copies of the resident rows / of the query batch
     int ks16 = -1;                           // 32-dimension fp16 steps per padded row (-1: no fp16 scan)
@@ -832,11 +833,14 @@ static void fill_rerank_params(dpf_index *ix, RerankParams &rp, const void *d_Qp
 }
 
 static const int32_t SEED_CAP = getenv("DPF_SEED_CAP") ? atoi(getenv("DPF_SEED_CAP")) : 256;     // seed sample per query
-// forwarded candidates per query before the gather path takes over (DPF_EMIT_CAP overrides, for tests)
-static int32_t emit_cap_setting()
+// Forwarded candidates a query's list holds before the gather path answers the query instead.  The
+// handle starts at 8192 and doubles the lists (up to 65536) after a batch in which a list overflowed;
+// DPF_EMIT_CAP pins the value (tests).
+static int32_t emit_cap_setting(const dpf_index *ix)
 {
     const char *e = getenv("DPF_EMIT_CAP");
-    int v = e ? atoi(e) : 8192;
+    if (!e) return ix->emit_cap;
+    const int v = atoi(e);
     return v < 1 ? 1 : v;
 }
 
@@ -848,7 +852,7 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
                                  int32_t steps, int32_t k, int32_t *d_ids, double *d_scores, hipStream_t stream, bool *done)
 {
     *done = false;
-    const int32_t EMIT_CAP = emit_cap_setting();
+    const int32_t EMIT_CAP = emit_cap_setting(ix);
     const int L = ix->cfg.num_tables;
     const int64_t nl = ix->num_leaves;
     HIPCHECK(ix, ix->ws_hashes.ensure((size_t)nq * L * 4));
@@ -1013,7 +1017,7 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     HIPCHECK(ix, hipEventRecord(ix->ev_scan[3], stream));
     HIPCHECK(ix, ix->ws_ovf.ensure((size_t)nq * 4));
     launch_overflow_list(ix->ws_emit_cnt.as<int32_t>(), nq, EMIT_CAP, ix->ws_flag.as<int32_t>(), ix->ws_ovf.as<int32_t>(), stream);
-    HIPCHECK(ix, hipMemcpyAsync(ix->pinned + 1, ix->ws_flag.p, 4, hipMemcpyDeviceToHost, stream));
+    HIPCHECK(ix, hipMemcpyAsync(ix->pinned + 4, ix->ws_flag.p, 16, hipMemcpyDeviceToHost, stream));
     HIPCHECK(ix, hipStreamSynchronize(stream));
     ix->st.last_pairs = pairs;
     if (getenv("DPF_DEBUG")) {
@@ -1025,15 +1029,18 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     }
     // Queries whose forward list overflowed are answered by the gather path afterwards, as a batch of
     // their own; when they are many the whole batch goes that way.
-    const int64_t n_ovf = (int32_t)(ix->pinned[1] & 0xffffffff);
+    const int64_t n_ovf = (int32_t)(ix->pinned[4] & 0xffffffff);
+    const int32_t longest = (int32_t)(ix->pinned[5] & 0xffffffff);
     ix->st.last_overflowed = n_ovf;
+    if (n_ovf > 0 && !getenv("DPF_EMIT_CAP") && ix->emit_cap < 65536) ix->emit_cap *= 2;   // from the next batch on
     if (n_ovf * 8 > nq) return DPF_OK;
 
     // distinct ids of every forward list (a row is forwarded once per tree it was found in)
-    const bool dedupe = 2 * (size_t)EMIT_CAP * 4 <= 128 * 1024;       // the table of the longest possible list fits LDS
+    const bool dedupe = unique_lists_lds(std::min(longest, EMIT_CAP)) <= 128 * 1024;   // the table of the longest list fits LDS
     if (dedupe) {
         HIPCHECK(ix, ix->ws_emit_ucnt.ensure((size_t)nq * 4));
-        launch_unique_lists(ix->ws_emit.as<int32_t>(), ix->ws_emit_cnt.as<int32_t>(), EMIT_CAP, ix->ws_emit_ucnt.as<int32_t>(), nq, stream);
+        launch_unique_lists(ix->ws_emit.as<int32_t>(), ix->ws_emit_cnt.as<int32_t>(), EMIT_CAP, longest, ix->ws_emit_ucnt.as<int32_t>(), nq,
+                            stream);
     }
     fill_rerank_params(ix, rp, qpad, k, nullptr, dedupe ? ix->ws_emit_ucnt.as<int32_t>() : ix->ws_emit_cnt.as<int32_t>(),
                        ix->ws_emit.as<int32_t>(), d_ids, d_scores);

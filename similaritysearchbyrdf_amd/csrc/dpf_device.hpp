@@ -125,7 +125,9 @@ void launch_rows_to_f16(const float *src, int64_t src_stride, int dim, int64_t n
                          float *norms, float *errs, hipStream_t stream);
 void launch_tau(int metric, const double *seed_scores, const int32_t *seed_ids, int k, int64_t nq, const float *q16_norm,
                 const float *q16_err, const int32_t *qids, int ks, int32_t *tau, float4 *qc, hipStream_t stream);
-void launch_unique_lists(int32_t *emit, const int32_t *emit_cnt, int32_t cap, int32_t *unique_cnt, int64_t nq, hipStream_t stream);
+size_t unique_lists_lds(int32_t longest);
+void launch_unique_lists(int32_t *emit, const int32_t *emit_cnt, int32_t cap, int32_t longest, int32_t *unique_cnt, int64_t nq,
+                         hipStream_t stream);
 void launch_overflow_list(const int32_t *emit_cnt, int64_t nq, int32_t cap, int32_t *flag, int32_t *list, hipStream_t stream);
 void launch_gather_queries(const int32_t *list, int64_t n, const void *Q, int64_t row_bytes, const int32_t *qids, void *subQ,
                            int32_t *sub_qids, hipStream_t stream);

@@ -1575,11 +1575,17 @@ void launch_leafscan(int metric, const LeafScanParams &p, hipStream_t stream)
     else launch_leafscan_f16_m<1, 4>(p, stream);
 }
 
-// flag[0] = number of queries whose forward list overflowed, their indices in list[]
+// flag[0] = number of queries whose forward list overflowed, their indices in list[];
+// flag[2] = the longest forward list of the batch
 __global__ void k_overflow_list(const int32_t *__restrict__ emit_cnt, int64_t nq, int32_t cap, int32_t *flag, int32_t *__restrict__ list)
 {
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q < nq && emit_cnt[q] > cap) list[atomicAdd(flag, 1)] = (int32_t)q;
+    const int32_t c = q < nq ? emit_cnt[q] : 0;
+    if (c > cap) list[atomicAdd(flag, 1)] = (int32_t)q;
+    int32_t m = c;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(flag + 2, m);
 }
 
 void launch_overflow_list(const int32_t *emit_cnt, int64_t nq, int32_t cap, int32_t *flag, int32_t *list, hipStream_t stream)
@@ -1670,11 +1676,21 @@ __global__ __launch_bounds__(256) void k_unique_lists(int32_t *__restrict__ emit
     if (threadIdx.x == 0) unique_cnt[q] = s_out;
 }
 
-void launch_unique_lists(int32_t *emit, const int32_t *emit_cnt, int32_t cap, int32_t *unique_cnt, int64_t nq, hipStream_t stream)
+// LDS bytes the table of a list of `longest` ids needs
+size_t unique_lists_lds(int32_t longest)
+{
+    size_t T = 2;
+    while (T < 2 * (size_t)std::max(longest, 1)) T <<= 1;
+    return T * 4;
+}
+
+// longest = the longest list of the batch (at most cap): it sizes the table, and with it how many
+// workgroups a CU holds
+void launch_unique_lists(int32_t *emit, const int32_t *emit_cnt, int32_t cap, int32_t longest, int32_t *unique_cnt, int64_t nq,
+                         hipStream_t stream)
 {
     if (nq <= 0) return;
-    int T = 2;
-    while (T < 2 * cap) T <<= 1;
+    const size_t T = unique_lists_lds(std::min(longest, cap)) / 4;
     hipLaunchKernelGGL(k_unique_lists, dim3((unsigned)nq), dim3(256), (size_t)T * 4, stream, emit, emit_cnt, cap, unique_cnt);
 }
 
