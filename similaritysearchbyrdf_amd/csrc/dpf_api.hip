@@ -981,7 +981,7 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
                ix->ws_q16e.as<float>(), d_qids, ix->ks16, ix->ws_tau.as<int32_t>(), (float4 *)ix->ws_qc.p, stream);
     HIPCHECK(ix, ix->ws_units.ensure((size_t)std::max<int64_t>(nunits, 1) * 16));
     launch_units(ix->ws_lq_cnt.as<uint32_t>(), ix->ws_lq_off.as<int64_t>(), ix->d_leaf_tile0.as<uint32_t>(),
-                 (const uint4 *)ix->d_tiles.p, nl, ix->ws_unit_off.as<int64_t>(), (uint4 *)ix->ws_units.p, stream);
+                 (const uint4 *)ix->d_tiles.p, ix->nutiles, ix->ws_unit_off.as<int64_t>(), (uint4 *)ix->ws_units.p, stream);
     HIPCHECK(ix, ix->ws_emit_v.ensure((size_t)nq * EMIT_CAP * 4));
     LeafScanParams lp;
     lp.ids = ix->d_ids.as<int32_t>();

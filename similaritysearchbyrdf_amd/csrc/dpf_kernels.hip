@@ -1039,22 +1039,21 @@ __global__ __launch_bounds__(256) void k_unit_count(const uint32_t *__restrict__
     if (l < nl) leaf_units[l] = (int32_t)units_of_leaf(lq_cnt[l], leaf_tile0[l + 1] - leaf_tile0[l]);
 }
 
+// one thread per tile (a long bucket has thousands of them)
 __global__ __launch_bounds__(256) void k_units(const uint32_t *__restrict__ lq_cnt, const int64_t *__restrict__ lq_off,
                                                const uint32_t *__restrict__ leaf_tile0, const uint4 *__restrict__ tiles,
-                                               int64_t nl, const int64_t *__restrict__ unit_off, uint4 *__restrict__ units)
+                                               int64_t ntiles, const int64_t *__restrict__ unit_off, uint4 *__restrict__ units)
 {
-    const int64_t l = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (l >= nl) return;
-    const uint32_t cnt = lq_cnt[l];
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= ntiles) return;
+    const uint4 td = tiles[t];
+    const uint32_t l = td.x, cnt = lq_cnt[l];
     if (cnt == 0) return;
-    const uint32_t t0 = leaf_tile0[l], ntl = leaf_tile0[l + 1] - t0;
-    int64_t base = unit_off[l];
+    const uint32_t groups = (cnt + UNIT_QUERIES - 1u) / UNIT_QUERIES;
+    int64_t base = unit_off[l] + (int64_t)((uint32_t)t - leaf_tile0[l]) * groups;
     const uint32_t lqb = (uint32_t)lq_off[l];
-    for (uint32_t t = 0; t < ntl; t++) {
-        const uint4 td = tiles[t0 + t];
-        for (uint32_t c = 0; c < cnt; c += UNIT_QUERIES)
-            units[base++] = make_uint4(td.y, td.z | (min(UNIT_QUERIES, cnt - c) << 8), lqb + c, td.w);
-    }
+    for (uint32_t c = 0; c < cnt; c += UNIT_QUERIES)
+        units[base++] = make_uint4(td.y, td.z | (min(UNIT_QUERIES, cnt - c) << 8), lqb + c, td.w);
 }
 
 // a non-negative float rounded UP to 8 significant bits, as the upper half of a word
@@ -1094,10 +1093,10 @@ void launch_unit_count(const uint32_t *lq_cnt, const uint32_t *leaf_tile0, int64
     if (nl > 0) hipLaunchKernelGGL(k_unit_count, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, stream, lq_cnt, leaf_tile0, nl, leaf_units);
     launch_scan_i32(leaf_units, nl, unit_off, stream);
 }
-void launch_units(const uint32_t *lq_cnt, const int64_t *lq_off, const uint32_t *leaf_tile0, const uint4 *tiles, int64_t nl,
+void launch_units(const uint32_t *lq_cnt, const int64_t *lq_off, const uint32_t *leaf_tile0, const uint4 *tiles, int64_t ntiles,
                   const int64_t *unit_off, uint4 *units, hipStream_t stream)
 {
-    if (nl > 0) hipLaunchKernelGGL(k_units, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, stream, lq_cnt, lq_off, leaf_tile0, tiles, nl, unit_off, units);
+    if (ntiles > 0) hipLaunchKernelGGL(k_units, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, stream, lq_cnt, lq_off, leaf_tile0, tiles, ntiles, unit_off, units);
 }
 void launch_tile_maxnorm(uint4 *tiles, int64_t ntiles, const int32_t *ids, const float *norms, const float *errs, int64_t row_begin,
                          int64_t row_end, float *slot_norms, hipStream_t stream)
