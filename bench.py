@@ -266,7 +266,8 @@ def main():
                                    "bucket overflow %d, %d-step search, top-%d by %s" % (
                                        args.workload, X.shape[1], n, nq, ix.L, ix.pb, params["bucket_overflow"],
                                        steps, k, args.metric),
-                       "global_batch": nq, "parallelism": "%s%d" % (sharded.mode, world),
+                       "global_batch": nq, "parallelism": ("tables: %d query groups x %d table groups" % (sharded.qg, sharded.tg)) if sharded.mode == "tables"
+                       else "%s%d" % (sharded.mode, world),
                        "recall_at_10": recall, "fit_seconds": round(fit_s, 3),
                        "fit_ms_on_rank0": {"copy_in_and_hash": round(st["fit_ms_hash"], 1),
                                            "forest_build_on_device": round(st["fit_ms_forest"], 1)},

@@ -6,10 +6,14 @@ per array of the per-rank top-k lists, then a merge by score, then id, with
 repeated ids taken once):
 
 * "tables" (used when the forest has at least as many tables as there are
-  ranks): everything is replicated, rank r probes and scans only tables
-  [r*L/G, (r+1)*L/G).  A query's candidate set is the union over tables
-  (DensevectorRDFInit.scala:420,428), so the union of the per-rank sets is the
-  whole set.  Probe, scan and rerank work all divide by G.
+  ranks): everything is replicated; the G ranks form a grid of QG query groups
+  x TG table groups (grid_of), rank r = (r // TG, r % TG) answers the queries
+  of its query group from the tables [t*L/TG, (t+1)*L/TG) of its table group.
+  A query's candidate set is the union over tables
+  (DensevectorRDFInit.scala:420,428), so the union of the TG per-rank sets of
+  a query group is the whole set.  Table groups divide the scan (every rank
+  reads its tables' rows once, however few queries it serves); query groups
+  divide what is paid per query (hashing, seed thresholds, exact rerank).
 * "rows": the forest and the hash family are replicated, base rows are sharded
   contiguously, rank r owning ids [r*N/G, (r+1)*N/G).  Every rank hashes and
   probes the whole query batch but scores only the candidates inside its shard.
@@ -30,6 +34,29 @@ def shard_bounds(n, world, rank):
 def table_bounds(num_tables, world, rank):
     """Contiguous table shard of rank `rank`: [lo, hi)."""
     return num_tables * rank // world, num_tables * (rank + 1) // world
+
+
+def grid_of(world, num_tables):
+    """(query groups, table groups) for `world` ranks in "tables" mode: the largest divisor TG of world
+    with TG <= sqrt(3 * world) and TG <= num_tables (2 ranks: 1 x 2, 4: 2 x 2, 8: 2 x 4, measured best on
+    an MI355X), the other factor as query groups."""
+    tg = 1
+    for d in range(1, world + 1):
+        if world % d == 0 and d * d <= 3 * world and d <= num_tables:
+            tg = d
+    return world // tg, tg
+
+
+def merge_grid_host(ids, scores, qg, tg, nq, metric):
+    """Host-side merge of the gathered lists [G, ceil(nq / qg), k] of a QG x TG grid into [nq, k]:
+    used to rehearse the exchange on CPU tensors (gloo)."""
+    out_i, out_s = [], []
+    for j in range(qg):
+        lo, hi = shard_bounds(nq, qg, j)
+        mi, ms = merge_topk_host(ids[j * tg:(j + 1) * tg, :hi - lo], scores[j * tg:(j + 1) * tg, :hi - lo], metric)
+        out_i.append(mi)
+        out_s.append(ms)
+    return np.concatenate(out_i), np.concatenate(out_s)
 
 
 def merge_topk_host(ids, scores, metric):
@@ -79,14 +106,18 @@ class ShardedDpf:
     """One rank's share of a sharded index on its GPU (see the module docstring for the two modes)."""
 
     def __init__(self, params, n_total, metric="l2", top_k=10, dtype=np.float32, device=0, rank=0, world=1,
-                 group=None, mode=None):
+                 group=None, mode=None, grid=None):
         from ._lib import DpfIndex
         self.rank, self.world, self.group, self.metric = rank, world, group, metric
         L = num_tables_of(params)
         self.mode = mode or ("tables" if world > 1 and L >= world else "rows")
+        self.qg, self.tg = 1, world
         if self.mode == "tables":
+            self.qg, self.tg = grid or grid_of(world, L)
+            if self.qg * self.tg != world:
+                raise ValueError("grid %r does not cover %d ranks" % ((self.qg, self.tg), world))
             self.lo, self.hi = 0, n_total
-            self.t_lo, self.t_hi = table_bounds(L, world, rank)
+            self.t_lo, self.t_hi = table_bounds(L, self.tg, rank % self.tg)
             self.index = DpfIndex(params, metric=metric, top_k=top_k, dtype=dtype, device=device,
                                   table_begin=self.t_lo, table_end=self.t_hi)
         else:
@@ -109,13 +140,31 @@ class ShardedDpf:
             self.index.query_topk_device(d_qids.data_ptr(), d_Q.data_ptr(), nq, steps, k, out_ids.data_ptr(),
                                          out_scores.data_ptr(), stream)
             return
-        if self._bufs is None or self._bufs[0].shape != (nq, k):
+        qg, tg = self.qg, self.tg
+        q_lo, q_hi = shard_bounds(nq, qg, self.rank // tg)        # this rank's query group
+        m = -(-nq // qg)                                           # rows every rank contributes to the exchange
+        if self._bufs is None or self._bufs[0].shape != (m, k):
             dev = d_Q.device
-            self._bufs = (torch.empty((nq, k), dtype=torch.int32, device=dev),
-                          torch.empty((nq, k), dtype=torch.float64, device=dev))
-        l_ids, l_sc = self._bufs
-        self.index.query_topk_device(d_qids.data_ptr(), d_Q.data_ptr(), nq, steps, k, l_ids.data_ptr(),
-                                     l_sc.data_ptr(), stream)
-        g_ids, g_sc = exchange(l_ids, l_sc, self.group)
-        self.index.merge_topk_device(g_ids.data_ptr(), g_sc.data_ptr(), self.world, nq, k, out_ids.data_ptr(),
-                                     out_scores.data_ptr(), stream)
+            self._bufs = (torch.full((m, k), -1, dtype=torch.int32, device=dev),
+                          torch.zeros((m, k), dtype=torch.float64, device=dev),
+                          torch.empty((m, k), dtype=torch.int32, device=dev),
+                          torch.empty((m, k), dtype=torch.float64, device=dev))
+        l_ids, l_sc, t_ids, t_sc = self._bufs
+        if q_hi > q_lo:
+            qid_ptr = d_qids[q_lo:q_hi].data_ptr() if d_qids is not None else None
+            self.index.query_topk_device(qid_ptr, d_Q[q_lo:q_hi].data_ptr(), q_hi - q_lo, steps, k, l_ids.data_ptr(),
+                                         l_sc.data_ptr(), stream)
+        g_ids, g_sc = exchange(l_ids, l_sc, self.group)            # [G, m, k]
+        for j in range(qg):
+            lo, hi = shard_bounds(nq, qg, j)
+            if hi == lo:
+                continue
+            src_i, src_s = g_ids[j * tg:(j + 1) * tg], g_sc[j * tg:(j + 1) * tg]
+            if hi - lo == m:
+                self.index.merge_topk_device(src_i.data_ptr(), src_s.data_ptr(), tg, m, k, out_ids[lo:hi].data_ptr(),
+                                             out_scores[lo:hi].data_ptr(), stream)
+            else:                                                  # a short last group: merge all m rows aside
+                self.index.merge_topk_device(src_i.data_ptr(), src_s.data_ptr(), tg, m, k, t_ids.data_ptr(),
+                                             t_sc.data_ptr(), stream)
+                out_ids[lo:hi].copy_(t_ids[:hi - lo])
+                out_scores[lo:hi].copy_(t_sc[:hi - lo])

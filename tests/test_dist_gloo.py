@@ -75,6 +75,71 @@ def _worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
+def _grid_worker(rank, world, port, ret):
+    """Tables mode on a grid of query groups x table groups: each rank answers its query group from
+    its table group; one all-gather, then a merge per query group."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import oracle as O
+        from similaritysearchbyrdf_amd.dist import (shard_bounds, table_bounds, num_tables_of, exchange, merge_grid_host,
+                                                    grid_of)
+        from tests.common import make_problem
+        params, X, Q, pick = make_problem(n=2501, nq=23, bucket_overflow=30, table_num=2, permutation_num=2)
+        L = num_tables_of(params)
+        qg, tg = grid_of(world, L)
+        assert qg * tg == world and tg > 1 and qg > 1
+        nq = len(pick)
+        orc = O.OracleIndex(params)
+        orc.fit(X.astype(np.float64), threads=2)
+        Q64 = Q.astype(np.float64)
+        off, ids = orc.query_batch(pick, Q64, steps=1, threads=2)
+        q_lo, q_hi = shard_bounds(nq, qg, rank // tg)
+        t_lo, t_hi = table_bounds(L, tg, rank % tg)
+        m = -(-nq // qg)
+        for metric in ("l2", "dot"):
+            loc, loc_off = [], [0]
+            for q in range(q_lo, q_hi):
+                per_table = [orc.get_similar(t, int(pick[q]), Q64[q], 1) for t in range(t_lo, t_hi)]
+                c = np.unique(np.concatenate(per_table)) if per_table else np.zeros(0, dtype=np.int32)
+                loc.append(c.astype(np.int32))
+                loc_off.append(loc_off[-1] + len(c))
+            loc_ids = np.concatenate(loc) if loc else np.zeros(0, dtype=np.int32)
+            pi, ps = orc.topk(Q64[q_lo:q_hi], np.asarray(loc_off), loc_ids, k=10, metric=metric, threads=2)
+            l_ids = np.full((m, 10), -1, dtype=np.int32)
+            l_sc = np.zeros((m, 10))
+            l_ids[:q_hi - q_lo], l_sc[:q_hi - q_lo] = pi, ps
+            g_ids, g_sc = exchange(torch.from_numpy(l_ids), torch.from_numpy(l_sc))
+            m_ids, m_sc = merge_grid_host(g_ids.numpy(), g_sc.numpy(), qg, tg, nq, metric)
+            want_ids, want_sc = orc.topk(Q64, off, ids, k=10, metric=metric, threads=2)
+            assert np.array_equal(m_ids, want_ids), metric
+            assert np.array_equal(np.nan_to_num(m_sc), np.nan_to_num(want_sc)), metric
+        ret[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+def test_query_by_table_grid_gloo():
+    world = 4
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_grid_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert [ret.get(r) for r in range(world)] == ["ok"] * world
+
+
+def test_grid_of():
+    from similaritysearchbyrdf_amd.dist import grid_of
+    assert grid_of(1, 30) == (1, 1) and grid_of(2, 30) == (1, 2) and grid_of(4, 30) == (2, 2) and grid_of(8, 30) == (2, 4)
+    assert grid_of(8, 1) == (8, 1) and grid_of(8, 3) == (4, 2) and grid_of(3, 30) == (1, 3)
+    for w in range(1, 33):
+        for L in (1, 2, 30):
+            q, t = grid_of(w, L)
+            assert q * t == w and t <= L
+
+
 @pytest.mark.parametrize("world", [2])
 def test_sharded_exchange_and_merge_gloo(world):
     mgr = mp.Manager()

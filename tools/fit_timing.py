@@ -4,7 +4,8 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import bench
 from similaritysearchbyrdf_amd._lib import DpfIndex
 
