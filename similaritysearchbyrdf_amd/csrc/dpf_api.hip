@@ -832,6 +832,10 @@ static void fill_rerank_params(dpf_index *ix, RerankParams &rp, const void *d_Qp
     rp.out_ids = d_ids; rp.out_scores = d_scores;
 }
 
+// ws_flag: 16 bytes of flags ([0] overflowed lists, [1] truncated bucket lists, [2] longest forward list), then the
+// ticket counters of the two scan launches (each counter on a 128-byte line of its own)
+static const int TICKET_COUNTERS = 16;
+static const size_t FLAG_BYTES = 16 + 2 * (size_t)TICKET_COUNTERS * 128;
 static const int32_t SEED_CAP = getenv("DPF_SEED_CAP") ? atoi(getenv("DPF_SEED_CAP")) : 256;     // seed sample per query
 // Forwarded candidates a query's list holds before the gather path answers the query instead.  The
 // handle starts at 8192 and doubles the lists (up to 65536) after a batch in which a list overflowed;
@@ -868,7 +872,7 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     HIPCHECK(ix, ix->ws_seed_scores.ensure((size_t)nq * k * 8));
     HIPCHECK(ix, ix->ws_emit.ensure((size_t)nq * EMIT_CAP * 4));
     HIPCHECK(ix, ix->ws_emit_cnt.ensure((size_t)nq * 4));
-    HIPCHECK(ix, ix->ws_flag.ensure(16));
+    HIPCHECK(ix, ix->ws_flag.ensure(FLAG_BYTES));
     HIPCHECK(ix, ix->ws_tau.ensure((size_t)nq * 4));
 
     if (ix->profiling) HIPCHECK(ix, hipEventRecord(ix->ev[0], stream));
@@ -876,7 +880,7 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     if (ix->profiling) HIPCHECK(ix, hipEventRecord(ix->ev[1], stream));
     HIPCHECK(ix, hipMemsetAsync(ix->ws_lq_cnt.p, 0, (size_t)(nl + 1) * 4, stream));
     HIPCHECK(ix, hipMemsetAsync(ix->ws_emit_cnt.p, 0, (size_t)nq * 4, stream));
-    HIPCHECK(ix, hipMemsetAsync(ix->ws_flag.p, 0, 16, stream));
+    HIPCHECK(ix, hipMemsetAsync(ix->ws_flag.p, 0, FLAG_BYTES, stream));
     ProbeParams pp;
     fill_probe_params(ix, pp, d_qids, steps);
     pp.lq_cnt = ix->ws_lq_cnt.as<uint32_t>();
@@ -997,8 +1001,8 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     lp.slot_norm = ix->d_slot_norm.as<float>(); lp.qc = (const float4 *)ix->ws_qc.p;
     lp.units = (const uint4 *)ix->ws_units.p;
     lp.num_cus = ix->num_cus; lp.ks = ix->ks16;
-    static const int xcds = getenv("DPF_XCDS") ? std::max(1, atoi(getenv("DPF_XCDS"))) : 1;
-    lp.num_xcd = ix->num_cus % xcds == 0 ? xcds : 1;
+    lp.num_counters = TICKET_COUNTERS;
+    lp.tickets = (unsigned int *)((char *)ix->ws_flag.p + 16);
     // a first slice of the units, then thresholds refined from what it forwarded, then the rest
     static const int first_permille = getenv("DPF_FIRST_PASS") ? atoi(getenv("DPF_FIRST_PASS")) : 100;
     const int64_t n_first = std::min<int64_t>(nunits, nunits * first_permille / 1000);
@@ -1012,6 +1016,7 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
         ix->scan_launches = 2;
     }
     lp.unit_begin = n_first; lp.unit_end = nunits;
+    lp.tickets += TICKET_COUNTERS * 32;                   // the second launch's own counters
     HIPCHECK(ix, hipEventRecord(ix->ev_scan[2], stream));
     launch_leafscan(ix->cfg.metric, lp, stream);
     HIPCHECK(ix, hipEventRecord(ix->ev_scan[3], stream));

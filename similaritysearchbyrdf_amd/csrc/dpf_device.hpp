@@ -86,7 +86,8 @@ struct LeafScanParams {
     const uint4 *units;          // work units of the batch, see k_units
     int64_t unit_begin, unit_end; // the slice of units[] this launch works through
     int32_t num_cus;
-    int32_t num_xcd;             // accelerator dies the workgroups are dealt over (1: plain striding)
+    unsigned int *tickets;       // num_counters ticket counters of this launch, 32 words apart, zeroed
+    int32_t num_counters;
     int32_t ks;
 };
 

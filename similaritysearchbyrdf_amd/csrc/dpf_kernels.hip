@@ -1307,7 +1307,7 @@ __device__ __forceinline__ void leafscan_flush_rest(const LeafScanParams &p, con
     }
 }
 
-// Persistent waves; wave w takes units w, w + W, w + 2W, ...  A unit needs two dependent levels
+// Persistent waves drawing units from ticket counters.  A unit needs two dependent levels
 // of loads (descriptor -> ids / query indices -> rows / query rows): descriptors run two units
 // ahead and ids one, query indices one 16-query chunk ahead, so a wave waits once per unit (rows +
 // first queries) and once per further chunk; the other waves of the SIMD fill those waits.
@@ -1326,16 +1326,24 @@ __global__ __launch_bounds__(256, ls16_waves(KS, RB)) void k_leafscan_f16(LeafSc
     __shared__ int32_t s_qid[4][16];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // Workgroups go round-robin over the XCDs; each XCD works through its own contiguous share of the
-    // unit list with all its waves side by side, so that at any moment an XCD's L2 serves the queries of
-    // a few hundred neighbouring buckets (which share most of them) instead of the whole batch.
-    const uint32_t nx = (uint32_t)p.num_xcd, xcd = blockIdx.x % nx, slot = blockIdx.x / nx;
-    const uint32_t per = ((uint32_t)((p.unit_end - p.unit_begin + nx - 1) / nx) + 3u) & ~3u;
-    const uint32_t lo = (uint32_t)p.unit_begin + xcd * per;
-    const uint32_t nunits = min((uint32_t)p.unit_end, lo + per);
-    const uint32_t W = (gridDim.x / nx) * 4u;
-    uint32_t u = lo + slot * 4u + (uint32_t)wave;
+    // Units are handed out dynamically, so that a wave that drew long units takes fewer: NC ticket counters,
+    // counter c serves the units u = unit_begin + t * NC + c (t = 0, 1, ...) to the workgroups with
+    // blockIdx % NC == c.  A wave's first three tickets are fixed (its place among the counter's waves, plus
+    // one and two rounds), later ones come from atomicAdd, fetched one unit ahead of the descriptor they are
+    // needed for.  Tickets only grow, so a wave stops at its first unit past the end.
+    const uint32_t nunits = (uint32_t)p.unit_end;
+    const uint32_t nc = (uint32_t)p.num_counters, cidx = blockIdx.x % nc;
+    const uint32_t place = (blockIdx.x / nc) * 4u + (uint32_t)wave;
+    const uint32_t places = ((gridDim.x - cidx + nc - 1u) / nc) * 4u;          // waves served by this counter
+    unsigned int *ctr = p.tickets + cidx * 32u;
+    auto unit_of = [&](uint32_t t) {
+        const unsigned long long uu = (unsigned long long)p.unit_begin + (unsigned long long)t * nc + cidx;
+        return uu < (unsigned long long)nunits ? (uint32_t)uu : nunits;
+    };
+    uint32_t u = unit_of(place), u_next = unit_of(place + places), u_after = unit_of(place + 2u * places);
     if (u >= nunits) return;
+    uint32_t pend = 0;
+    if (lane == 0) pend = atomicAdd(ctr, 1u);
     const int i16 = lane & 15, g = lane >> 4;
     // Query j of a 16-query chunk sits in MFMA row 4*(j%4) + j/4, so that the accumulator register
     // r of every lane belongs to queries 4r..4r+3 and a chunk of n queries needs only its first
@@ -1358,11 +1366,11 @@ __global__ __launch_bounds__(256, ls16_waves(KS, RB)) void k_leafscan_f16(LeafSc
         qs = jq < nq ? p.leaf_queries[U.z + jq] : -1;
     };
 
-    uint4 U0 = desc(u), U1 = desc(u + W);
+    uint4 U0 = desc(u), U1 = desc(u_next);
     int32_t id0[RB], qs0;
     small(U0, id0, qs0);
 
-    for (; u < nunits; u += W) {
+    for (; u < nunits;) {
         // this unit's rows
         f16x8 xb[RB][KS];
         float nJ[RB];                                     // minus the row's share of the threshold, -|x~|^2 (1 - c32) / 2;
@@ -1392,7 +1400,11 @@ __global__ __launch_bounds__(256, ls16_waves(KS, RB)) void k_leafscan_f16(LeafSc
         // the second chunk's query indices ride along with the rows
         const int32_t qsc = qs0, qsn = 16u + jq < nq ? p.leaf_queries[lq0 + 16u + jq] : -1;
         U0 = U1;
-        U1 = desc(u + 2u * W);
+        U1 = desc(u_after);
+        u = u_next;
+        u_next = u_after;
+        u_after = unit_of(3u * places + (uint32_t)__builtin_amdgcn_readfirstlane((int)pend));
+        if (lane == 0) pend = atomicAdd(ctr, 1u);
         small(U0, id0, qs0);
         leafscan_chunks<KS, METRIC, RB>(p, Q16, xb, nJ, idj, rows, nq, lq0, xrm, cxm, qsc, qsn, s_fq[wave], s_fid[wave], s_fv[wave],
                                         s_slot[wave], s_G[wave], s_qid[wave], nbuf);
@@ -1406,10 +1418,10 @@ static void launch_leafscan_f16_m(const LeafScanParams &p, hipStream_t stream)
     const int64_t n = p.unit_end - p.unit_begin;
     if (n <= 0) return;
     const int64_t resident = (int64_t)p.num_cus * ls16_waves(p.ks, RB);   // workgroups the chip holds at once
-    // a multiple of the XCD count, so that every XCD gets the same number of workgroups
-    const int64_t nx = p.num_xcd;
-    dim3 grid((unsigned)(std::min<int64_t>(((n + 3) / 4 + nx - 1) / nx * nx, resident / nx * nx))), block(256);
-#define DPF_LB(KS) hipLaunchKernelGGL((k_leafscan_f16<KS, METRIC, RB>), grid, block, 0, stream, p, p.Q16, p.base16)
+    dim3 grid((unsigned)std::min<int64_t>((n + 3) / 4, resident)), block(256);
+    LeafScanParams q = p;
+    q.num_counters = (int32_t)std::min<int64_t>(p.num_counters, grid.x);     // every counter needs a workgroup
+#define DPF_LB(KS) hipLaunchKernelGGL((k_leafscan_f16<KS, METRIC, RB>), grid, block, 0, stream, q, q.Q16, q.base16)
     switch (p.ks) {
     case 1: DPF_LB(1); break;
     case 2: DPF_LB(2); break;
