@@ -330,7 +330,7 @@ __global__ __launch_bounds__(1024) void k_probe(ProbeParams p)
             const uint32_t seg = h >> p.bucket_bits;
             const uint32_t *roots = p.roots + ((size_t)t * P) * p.seg + seg;
             // what is done with one lane's bucket (every lane calls it, with NO_LEAF when it has none)
-            auto take = [&](uint32_t leaf) {
+            auto take = [&](uint32_t leaf, bool own_bucket) {
                 uint32_t beg = 0, end = 0;
                 if (leaf != NO_LEAF) { beg = p.leaf_off[leaf]; end = p.leaf_off[leaf + 1]; }
                 if (MODE == 0) {
@@ -340,7 +340,9 @@ __global__ __launch_bounds__(1024) void k_probe(ProbeParams p)
                         const uint32_t place = atomicAdd(&p.lq_cnt[leaf], 1u);
                         if (p.q_leaves) {
                             const uint32_t pos = atomicAdd(&s_nleaf, 1u);
-                            if (pos < (uint32_t)p.q_leaf_cap) p.q_leaves[q * p.q_leaf_cap + pos] = make_uint2(leaf, place);
+                            // top bit: the bucket the query itself would be stored in (same sub-index, same path)
+                            if (pos < (uint32_t)p.q_leaf_cap)
+                                p.q_leaves[q * p.q_leaf_cap + pos] = make_uint2(leaf, place | (own_bucket ? 0x80000000u : 0u));
                         }
                     }
                 } else if (MODE == 2) {
@@ -423,15 +425,17 @@ __global__ __launch_bounds__(1024) void k_probe(ProbeParams p)
                 // level - then the probe ends in a subtree no other probe enters - or it lies below
                 // the level where the path ends (or in bits the trie does not use) and the probe ends
                 // in the query's own bucket.  So only the own bucket can be reached more than once.
+                bool own_hit[2];
 #pragma unroll
                 for (int k = 0; k < 2; k++) {
                     const uint32_t own = __shfl(leaf[k], (lane & 32) + 31);
                     if (i == 31) leaf[k] = NO_LEAF;
                     const unsigned long long same = __ballot(leaf[k] != NO_LEAF && leaf[k] == own) >> (lane & 32);
                     if (leaf[k] == own && (same & ((1ull << i) - 1ull) & 0xffffffffull)) leaf[k] = NO_LEAF;
+                    own_hit[k] = leaf[k] != NO_LEAF && leaf[k] == own && (k ? sB : sA) == part;
                 }
-                take(leaf[0]);
-                take(leaf[1]);
+                take(leaf[0], own_hit[0]);
+                take(leaf[1], own_hit[1]);
             }
         }
         if (MODE != 1) break;
@@ -502,21 +506,29 @@ __global__ __launch_bounds__(1024) void k_probe(ProbeParams p)
 // first buckets into its seed sample.  Only launched when no query's list was truncated.
 __global__ __launch_bounds__(256) void k_fill_lists(ProbeParams p)
 {
-    __shared__ uint32_t s_seed;
+    __shared__ uint32_t s_seed, s_nown;
+    __shared__ uint32_t s_own[256];
     const int64_t q = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = min(p.q_leaf_cnt[q], p.q_leaf_cap);
     const int32_t qid = p.qids ? p.qids[q] : -1;
-    if (tid == 0) s_seed = 0;
+    if (tid == 0) { s_seed = 0; s_nown = 0; }
     __syncthreads();
     const uint2 *mine = p.q_leaves + q * p.q_leaf_cap;
     for (int j = tid; j < n; j += 256) {
-        const uint2 lp = mine[j];                         // {bucket, place in the bucket's list}
-        p.leaf_queries[p.lq_off[lp.x] + lp.y] = (int32_t)q;
+        const uint2 lp = mine[j];                         // {bucket, place in the bucket's list | own-bucket flag}
+        p.leaf_queries[p.lq_off[lp.x] + (lp.y & 0x7fffffffu)] = (int32_t)q;
+        if (lp.y & 0x80000000u) {
+            const uint32_t at = atomicAdd(&s_nown, 1u);
+            if (at < 256u) s_own[at] = lp.x;
+        }
     }
-    for (int j = wave; j < n && s_seed < (uint32_t)p.seed_cap; j += 4) {
-        const uint32_t leaf = mine[j].x;
-        const uint32_t b = p.leaf_off[leaf], e = p.leaf_off[leaf + 1];
+    __syncthreads();
+    // Seed sample.  First an equal share from each of the query's OWN buckets (one per table: the rows that
+    // collide with the query on the whole hash are its likeliest neighbours, and a true neighbour sits in
+    // several of them), then whole buckets in list order until the sample is full.
+    auto copy_from = [&](uint32_t leaf, uint32_t most) {
+        const uint32_t b = p.leaf_off[leaf], end = p.leaf_off[leaf + 1], e = most < end - b ? b + most : end;
         for (uint32_t k0 = b; k0 < e; k0 += 64) {
             const uint32_t k = k0 + lane;
             const int32_t id = k < e ? p.ids[k] : -1;
@@ -530,7 +542,15 @@ __global__ __launch_bounds__(256) void k_fill_lists(ProbeParams p)
             const uint32_t at = at0 + __popcll(m & ((1ull << lane) - 1ull));
             if (ok && at < (uint32_t)p.seed_cap) p.seed_cand[q * p.seed_cap + at] = id;
         }
+    };
+    const uint32_t nown = min(s_nown, 256u);
+    if (nown > 0) {
+        const uint32_t share = ((uint32_t)p.seed_cap + nown - 1u) / nown;
+        for (uint32_t j = wave; j < nown; j += 4) copy_from(s_own[j], share);
     }
+    __syncthreads();
+    for (int j = wave; j < n && s_seed < (uint32_t)p.seed_cap; j += 4)
+        if (!(mine[j].y & 0x80000000u)) copy_from(mine[j].x, 0xffffffffu);
     __syncthreads();
     if (tid == 0) p.seed_cnt[q] = s_seed < (uint32_t)p.seed_cap ? (int32_t)s_seed : p.seed_cap;
 }
