@@ -38,11 +38,11 @@ def table_bounds(num_tables, world, rank):
 
 def grid_of(world, num_tables):
     """(query groups, table groups) for `world` ranks in "tables" mode: the largest divisor TG of world
-    with TG <= sqrt(3 * world) and TG <= num_tables (2 ranks: 1 x 2, 4: 2 x 2, 8: 2 x 4, measured best on
+    with TG <= 2 * sqrt(world) and TG <= num_tables (2 ranks: 1 x 2, 4: 1 x 4, 8: 2 x 4, measured best on
     an MI355X), the other factor as query groups."""
     tg = 1
     for d in range(1, world + 1):
-        if world % d == 0 and d * d <= 3 * world and d <= num_tables:
+        if world % d == 0 and d * d <= 4 * world and d <= num_tables:
             tg = d
     return world // tg, tg
 
