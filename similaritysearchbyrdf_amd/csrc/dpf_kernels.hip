@@ -318,124 +318,151 @@ __global__ __launch_bounds__(1024) void k_probe(ProbeParams p)
         }
         __syncthreads();
 
-        for (int t = p.t_begin + wave; t < p.t_end; t += nwaves) {
-            const uint32_t h = (uint32_t)p.hashes[q * p.L + t];
-            const int part = p.parts[q * p.L + t];
-            // RDT:753: 32 - numberOfLeadingZeros(h) - 4 probes; negative for 0 <= h < 8
-            const int nprobe = 32 - (h ? __clz(h) : 32) - 4;
-            if (nprobe <= 0) {
-                if (nprobe < 0 && lane == 0 && c == 0 && MODE == 0) atomicAdd(p.short_hash_events, 1ull);
-                continue;
+        // A wave works on two tables at a time: each lane then has four independent walks in flight (two
+        // sub-indexes of each table), whose dependent 4-byte reads overlap.
+        // what is done with one lane's bucket (every lane calls it, with NO_LEAF when it has none)
+        auto take = [&](uint32_t leaf, bool own_bucket) {
+            uint32_t beg = 0, end = 0;
+            if (leaf != NO_LEAF) { beg = p.leaf_off[leaf]; end = p.leaf_off[leaf + 1]; }
+            if (MODE == 0) {
+                raw_local += end - beg;
+                if (p.lq_cnt && end > beg) {
+                    // the old count is this query's place in the bucket's list
+                    const uint32_t place = atomicAdd(&p.lq_cnt[leaf], 1u);
+                    if (p.q_leaves) {
+                        const uint32_t pos = atomicAdd(&s_nleaf, 1u);
+                        // top bit: the bucket the query itself would be stored in (same sub-index, same path)
+                        if (pos < (uint32_t)p.q_leaf_cap)
+                            p.q_leaves[q * p.q_leaf_cap + pos] = make_uint2(leaf, place | (own_bucket ? 0x80000000u : 0u));
+                    }
+                }
+            } else if (MODE == 2) {
+                if (end > beg) {
+                    const uint32_t pos = atomicAdd(&p.lq_cursor[leaf], 1u);
+                    p.leaf_queries[p.lq_off[leaf] + pos] = (int32_t)q;
+                }
+                // seed sample: ids of the first buckets any wave reaches, up to seed_cap
+                // (duplicates across tables are harmless: the exact rerank keeps one)
+                unsigned long long mask = __ballot(end > beg);
+                while (mask && s_seed < (uint32_t)p.seed_cap) {
+                    const int src = __ffsll((long long)mask) - 1;
+                    mask &= mask - 1;
+                    const uint32_t b = __shfl(beg, src), e = __shfl(end, src);
+                    for (uint32_t k0 = b; k0 < e; k0 += 64) {
+                        const uint32_t k = k0 + lane;
+                        const int32_t id = k < e ? p.ids[k] : -1;
+                        const bool ok = k < e && id >= p.row_begin && id < p.row_end &&
+                                        !self_excluded(id, qid, p.exclude_self);
+                        const unsigned long long m = __ballot(ok);
+                        if (m == 0) continue;
+                        uint32_t at0 = 0;
+                        if (lane == 0) at0 = atomicAdd(&s_seed, (uint32_t)__popcll(m));
+                        at0 = __shfl(at0, 0);
+                        if (at0 >= (uint32_t)p.seed_cap) break;
+                        const uint32_t at = at0 + __popcll(m & ((1ull << lane) - 1ull));
+                        if (ok && at < (uint32_t)p.seed_cap) p.seed_cand[q * p.seed_cap + at] = id;
+                    }
+                }
+            } else {
+                unsigned long long mask = __ballot(leaf != NO_LEAF);
+                while (mask) {
+                    const int src = __ffsll((long long)mask) - 1;
+                    mask &= mask - 1;
+                    const uint32_t b = __shfl(beg, src), e = __shfl(end, src);
+                    for (uint32_t k = b + lane; k < e; k += 64) {
+                        const int32_t id = p.ids[k];
+                        if (id >= lo && id < hi && !self_excluded(id, qid, p.exclude_self)) {
+                            const uint32_t bit = (uint32_t)(id - lo);
+                            atomicOr(&lds[bit >> 5], 1u << (bit & 31));
+                        }
+                    }
+                }
             }
-            const uint32_t seg = h >> p.bucket_bits;
-            const uint32_t *roots = p.roots + ((size_t)t * P) * p.seg + seg;
-            // what is done with one lane's bucket (every lane calls it, with NO_LEAF when it has none)
-            auto take = [&](uint32_t leaf, bool own_bucket) {
-                uint32_t beg = 0, end = 0;
-                if (leaf != NO_LEAF) { beg = p.leaf_off[leaf]; end = p.leaf_off[leaf + 1]; }
-                if (MODE == 0) {
-                    raw_local += end - beg;
-                    if (p.lq_cnt && end > beg) {
-                        // the old count is this query's place in the bucket's list
-                        const uint32_t place = atomicAdd(&p.lq_cnt[leaf], 1u);
-                        if (p.q_leaves) {
-                            const uint32_t pos = atomicAdd(&s_nleaf, 1u);
-                            // top bit: the bucket the query itself would be stored in (same sub-index, same path)
-                            if (pos < (uint32_t)p.q_leaf_cap)
-                                p.q_leaves[q * p.q_leaf_cap + pos] = make_uint2(leaf, place | (own_bucket ? 0x80000000u : 0u));
-                        }
-                    }
-                } else if (MODE == 2) {
-                    if (end > beg) {
-                        const uint32_t pos = atomicAdd(&p.lq_cursor[leaf], 1u);
-                        p.leaf_queries[p.lq_off[leaf] + pos] = (int32_t)q;
-                    }
-                    // seed sample: ids of the first buckets any wave reaches, up to seed_cap
-                    // (duplicates across tables are harmless: the exact rerank keeps one)
-                    unsigned long long mask = __ballot(end > beg);
-                    while (mask && s_seed < (uint32_t)p.seed_cap) {
-                        const int src = __ffsll((long long)mask) - 1;
-                        mask &= mask - 1;
-                        const uint32_t b = __shfl(beg, src), e = __shfl(end, src);
-                        for (uint32_t k0 = b; k0 < e; k0 += 64) {
-                            const uint32_t k = k0 + lane;
-                            const int32_t id = k < e ? p.ids[k] : -1;
-                            const bool ok = k < e && id >= p.row_begin && id < p.row_end &&
-                                            !self_excluded(id, qid, p.exclude_self);
-                            const unsigned long long m = __ballot(ok);
-                            if (m == 0) continue;
-                            uint32_t at0 = 0;
-                            if (lane == 0) at0 = atomicAdd(&s_seed, (uint32_t)__popcll(m));
-                            at0 = __shfl(at0, 0);
-                            if (at0 >= (uint32_t)p.seed_cap) break;
-                            const uint32_t at = at0 + __popcll(m & ((1ull << lane) - 1ull));
-                            if (ok && at < (uint32_t)p.seed_cap) p.seed_cand[q * p.seed_cap + at] = id;
-                        }
-                    }
-                } else {
-                    unsigned long long mask = __ballot(leaf != NO_LEAF);
-                    while (mask) {
-                        const int src = __ffsll((long long)mask) - 1;
-                        mask &= mask - 1;
-                        const uint32_t b = __shfl(beg, src), e = __shfl(end, src);
-                        for (uint32_t k = b + lane; k < e; k += 64) {
-                            const int32_t id = p.ids[k];
-                            if (id >= lo && id < hi && !self_excluded(id, qid, p.exclude_self)) {
-                                const uint32_t bit = (uint32_t)(id - lo);
-                                atomicOr(&lds[bit >> 5], 1u << (bit & 31));
-                            }
-                        }
-                    }
-                }
-            };
-            // the sub-indexes within `steps` bit flips of the query's own, four per round: the lower
-            // half-wave walks the first and third, the upper the second and fourth, each lane two
-            // walks at a time so that their dependent loads overlap
-            uint32_t submask = 0;
-            for (int s = 0; s < P; s++)
-                if (__popc((uint32_t)(s ^ part)) <= p.steps) submask |= 1u << s;
-            // lane 31 of each half walks the unflipped hash: it is not a probe (RDT:753-758),
-            // it only names the query's own bucket for the collapse below
-            const bool act = i < nprobe || i == 31;
-            const uint32_t key = i == 31 ? h : h ^ (1u << i);
-            while (submask) {
-                int sub[4];
+        };
+        for (int t0 = p.t_begin + 2 * wave; t0 < p.t_end; t0 += 2 * nwaves) {
+            uint32_t key[2], submask[2] = {0u, 0u};
+            int part[2], nprobe[2];
+            const uint32_t *roots[2];
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    sub[k] = -1;
-                    if (submask) { sub[k] = __ffs((int)submask) - 1; submask &= submask - 1; }
+            for (int x = 0; x < 2; x++) {
+                const int t = t0 + x;
+                key[x] = 0; part[x] = 0; nprobe[x] = 0; roots[x] = p.roots;
+                if (t >= p.t_end) continue;
+                const uint32_t h = (uint32_t)p.hashes[q * p.L + t];
+                part[x] = p.parts[q * p.L + t];
+                // RDT:753: 32 - numberOfLeadingZeros(h) - 4 probes; negative for 0 <= h < 8
+                nprobe[x] = 32 - (h ? __clz(h) : 32) - 4;
+                if (nprobe[x] <= 0) {
+                    if (nprobe[x] < 0 && lane == 0 && c == 0 && MODE == 0) atomicAdd(p.short_hash_events, 1ull);
+                    continue;
                 }
-                const int sA = half ? sub[1] : sub[0], sB = half ? sub[3] : sub[2];
-                uint32_t leaf[2] = {NO_LEAF, NO_LEAF}, node[2];
-                node[0] = (act && sA >= 0) ? roots[(size_t)sA * p.seg] : 0u;
-                node[1] = (act && sB >= 0) ? roots[(size_t)sB * p.seg] : 0u;
-                for (int level = p.max_level; level >= 0 && (node[0] | node[1]); --level) {
-                    const uint32_t slot = (key >> (level * p.nbits)) & (uint32_t)(p.dns - 1);
-                    uint32_t w[2];
+                roots[x] = p.roots + ((size_t)t * P) * p.seg + (h >> p.bucket_bits);
+                // the sub-indexes within `steps` bit flips of the query's own
+                for (int s2 = 0; s2 < P; s2++)
+                    if (__popc((uint32_t)(s2 ^ part[x])) <= p.steps) submask[x] |= 1u << s2;
+                // lane 31 of each half walks the unflipped hash: it is not a probe (RDT:753-758),
+                // it only names the query's own bucket for the collapse below
+                key[x] = i == 31 ? h : h ^ (1u << i);
+            }
+            // four sub-indexes of each table per round: the lower half-wave walks the first and third, the
+            // upper the second and fourth
+            while (submask[0] | submask[1]) {
+                int sw[2][2];
+                uint32_t leaf[2][2], node[2][2];
 #pragma unroll
-                    for (int k = 0; k < 2; k++) w[k] = node[k] ? p.dnodes[(size_t)node[k] * p.dns + slot] : 0u;
+                for (int x = 0; x < 2; x++) {
+                    int sub[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        sub[k] = -1;
+                        if (submask[x]) { sub[k] = __ffs((int)submask[x]) - 1; submask[x] &= submask[x] - 1; }
+                    }
+                    sw[x][0] = half ? sub[1] : sub[0];
+                    sw[x][1] = half ? sub[3] : sub[2];
+                    const bool act = i < nprobe[x] || (i == 31 && nprobe[x] > 0);
 #pragma unroll
                     for (int k = 0; k < 2; k++) {
-                        if (w[k] & 1u) { leaf[k] = w[k] >> 1; node[k] = 0; }
-                        else node[k] = w[k] >> 1;
+                        leaf[x][k] = NO_LEAF;
+                        node[x][k] = (act && sw[x][k] >= 0) ? roots[x][(size_t)sw[x][k] * p.seg] : 0u;
                     }
+                }
+                for (int level = p.max_level; level >= 0 && (node[0][0] | node[0][1] | node[1][0] | node[1][1]); --level) {
+                    uint32_t w[2][2];
+#pragma unroll
+                    for (int x = 0; x < 2; x++) {
+                        const uint32_t slot = (key[x] >> (level * p.nbits)) & (uint32_t)(p.dns - 1);
+#pragma unroll
+                        for (int k = 0; k < 2; k++) w[x][k] = node[x][k] ? p.dnodes[(size_t)node[x][k] * p.dns + slot] : 0u;
+                    }
+#pragma unroll
+                    for (int x = 0; x < 2; x++)
+#pragma unroll
+                        for (int k = 0; k < 2; k++) {
+                            if (w[x][k] & 1u) { leaf[x][k] = w[x][k] >> 1; node[x][k] = 0; }
+                            else node[x][k] = w[x][k] >> 1;
+                        }
                 }
                 // Collapse probes that reached the same bucket (same sub-index only: buckets of
                 // different sub-indexes are disjoint).  A flipped bit either changes the path at its
                 // level - then the probe ends in a subtree no other probe enters - or it lies below
                 // the level where the path ends (or in bits the trie does not use) and the probe ends
                 // in the query's own bucket.  So only the own bucket can be reached more than once.
-                bool own_hit[2];
+                bool own_hit[2][2];
 #pragma unroll
-                for (int k = 0; k < 2; k++) {
-                    const uint32_t own = __shfl(leaf[k], (lane & 32) + 31);
-                    if (i == 31) leaf[k] = NO_LEAF;
-                    const unsigned long long same = __ballot(leaf[k] != NO_LEAF && leaf[k] == own) >> (lane & 32);
-                    if (leaf[k] == own && (same & ((1ull << i) - 1ull) & 0xffffffffull)) leaf[k] = NO_LEAF;
-                    own_hit[k] = leaf[k] != NO_LEAF && leaf[k] == own && (k ? sB : sA) == part;
+                for (int x = 0; x < 2; x++)
+#pragma unroll
+                    for (int k = 0; k < 2; k++) {
+                        const uint32_t own = __shfl(leaf[x][k], (lane & 32) + 31);
+                        if (i == 31) leaf[x][k] = NO_LEAF;
+                        const unsigned long long same = __ballot(leaf[x][k] != NO_LEAF && leaf[x][k] == own) >> (lane & 32);
+                        if (leaf[x][k] == own && (same & ((1ull << i) - 1ull) & 0xffffffffull)) leaf[x][k] = NO_LEAF;
+                        own_hit[x][k] = leaf[x][k] != NO_LEAF && leaf[x][k] == own && sw[x][k] == part[x];
+                    }
+#pragma unroll
+                for (int x = 0; x < 2; x++) {
+                    take(leaf[x][0], own_hit[x][0]);
+                    take(leaf[x][1], own_hit[x][1]);
                 }
-                take(leaf[0], own_hit[0]);
-                take(leaf[1], own_hit[1]);
             }
         }
         if (MODE != 1) break;
