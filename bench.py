@@ -135,6 +135,7 @@ def main():
     ap.add_argument("--rerank", default="auto", choices=["auto", "gather"],
                     help="auto: bucket-major bf16 scan + exact rerank where it applies; gather: per-query fp64 gather kernel")
     ap.add_argument("--verify", action="store_true", help="rank 0 also runs an unsharded index and compares the merged ids")
+    ap.add_argument("--grid", default=None, help="QxT: query groups x table groups of the tables mode (default: chosen from --gpus)")
     ap.add_argument("--backend", default="nccl", help="nccl (RCCL, one GPU per rank) or gloo (rehearsal: ranks may share a GPU)")
     args = ap.parse_args()
 
@@ -164,7 +165,9 @@ def main():
     if args.search_steps is not None:
         steps = args.search_steps
     n, nq, k = X.shape[0], Q.shape[0], args.k
-    sharded = ShardedDpf(params, n, metric=args.metric, top_k=k, dtype=np.float32, device=local, rank=rank, world=world)
+    grid = tuple(int(v) for v in args.grid.lower().split("x")) if args.grid else None
+    sharded = ShardedDpf(params, n, metric=args.metric, top_k=k, dtype=np.float32, device=local, rank=rank, world=world,
+                         grid=grid)
     ix = sharded.index
     t0 = time.time()
     sharded.fit(X)
