@@ -211,7 +211,9 @@ int dpf_snapshot_copy(dpf_index *ix, uint32_t *roots, uint32_t *dnodes, uint32_t
  * bucket-major path *ms and *algorithmic_bytes are sums over the scan kernel's
  * launches of the batch (dpf_stats.last_scan_launches of them). */
 int dpf_last_rerank_profile(dpf_index *ix, double *ms, int64_t *algorithmic_bytes);
-/* enable (1) / disable (0) the per-stage HIP-event timing (adds stream syncs) */
+/* enable (1) / disable (0) the per-stage HIP-event timing: the events are recorded only for batches
+ * that run while it is on (an event between two kernels costs a few microseconds of stream time);
+ * dpf_last_rerank_profile and the last_ms_* statistics need it on for the batch they describe */
 int dpf_set_profiling(dpf_index *ix, int32_t on);
 
 #ifdef __cplusplus

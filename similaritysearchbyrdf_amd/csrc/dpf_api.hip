@@ -115,6 +115,7 @@ struct dpf_index {
     hipEvent_t ev[6]{};
     int last_path = 0;
     bool profiling = false;
+    bool last_timed = false;                          // the last top-k batch recorded its events
     int64_t last_nq = 0;
     int32_t last_k = 0;
     bool last_valid = false;
@@ -1008,18 +1009,18 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     const int64_t n_first = std::min<int64_t>(nunits, nunits * first_permille / 1000);
     ix->scan_launches = 1;
     lp.unit_begin = 0; lp.unit_end = n_first;
-    HIPCHECK(ix, hipEventRecord(ix->ev_scan[0], stream));
+    if (ix->profiling) HIPCHECK(ix, hipEventRecord(ix->ev_scan[0], stream));
     launch_leafscan(ix->cfg.metric, lp, stream);
-    HIPCHECK(ix, hipEventRecord(ix->ev_scan[1], stream));
+    if (ix->profiling) HIPCHECK(ix, hipEventRecord(ix->ev_scan[1], stream));
     if (n_first > 0) {
         launch_refine(ix->cfg.metric, lp.emit, lp.emit_v, lp.emit_cnt, EMIT_CAP, k, nq, ix->ws_q16e.as<float>(), lp.tau, stream);
         ix->scan_launches = 2;
     }
     lp.unit_begin = n_first; lp.unit_end = nunits;
     lp.tickets += TICKET_COUNTERS * 32;                   // the second launch's own counters
-    HIPCHECK(ix, hipEventRecord(ix->ev_scan[2], stream));
+    if (ix->profiling) HIPCHECK(ix, hipEventRecord(ix->ev_scan[2], stream));
     launch_leafscan(ix->cfg.metric, lp, stream);
-    HIPCHECK(ix, hipEventRecord(ix->ev_scan[3], stream));
+    if (ix->profiling) HIPCHECK(ix, hipEventRecord(ix->ev_scan[3], stream));
     HIPCHECK(ix, ix->ws_ovf.ensure((size_t)nq * 4));
     launch_overflow_list(ix->ws_emit_cnt.as<int32_t>(), nq, EMIT_CAP, ix->ws_flag.as<int32_t>(), ix->ws_ovf.as<int32_t>(), stream);
     HIPCHECK(ix, hipMemcpyAsync(ix->pinned + 4, ix->ws_flag.p, 16, hipMemcpyDeviceToHost, stream));
@@ -1050,10 +1051,10 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     fill_rerank_params(ix, rp, qpad, k, nullptr, dedupe ? ix->ws_emit_ucnt.as<int32_t>() : ix->ws_emit_cnt.as<int32_t>(),
                        ix->ws_emit.as<int32_t>(), d_ids, d_scores);
     rp.cand_stride = EMIT_CAP;
-    HIPCHECK(ix, hipEventRecord(ix->ev[4], stream));
+    if (ix->profiling) HIPCHECK(ix, hipEventRecord(ix->ev[4], stream));
     if (short_lists && rerank_short_applies(rp)) launch_rerank_short(ix->cfg.dtype, ix->cfg.metric, rp, nq, stream);
     else launch_rerank(ix->cfg.dtype, ix->cfg.metric, rp, nq, stream);
-    HIPCHECK(ix, hipEventRecord(ix->ev[5], stream));
+    if (ix->profiling) HIPCHECK(ix, hipEventRecord(ix->ev[5], stream));
     HIPCHECK(ix, hipGetLastError());
     if (n_ovf > 0) {
         const int64_t row_bytes = ix->dpad * (int64_t)ix->elem;
@@ -1104,6 +1105,7 @@ extern "C" int dpf_query_topk_device(dpf_index *ix, const int32_t *d_qids, const
     // the rerank kernels read whole 16-byte pieces, so they always get padded rows
     if ((rc = pad_queries(ix, d_Q, nq, stream, &qpad, &qstride)) != DPF_OK) return rc;
     ix->last_k = k;
+    ix->last_timed = ix->profiling;
     if (ix->bucket_major && ix->ntiles > 0) {
         bool done = false;
         if ((rc = run_topk_bucket_major(ix, d_qids, qpad, qstride, nq, steps, k, d_ids, d_scores, stream, &done)) != DPF_OK) return rc;
@@ -1112,9 +1114,9 @@ extern "C" int dpf_query_topk_device(dpf_index *ix, const int32_t *d_qids, const
     if ((rc = run_probe(ix, d_qids, qpad, qstride, nq, steps, stream)) != DPF_OK) return rc;
     RerankParams rp;
     fill_rerank_params(ix, rp, qpad, k, ix->ws_off.as<int64_t>(), ix->ws_cnt.as<int32_t>(), ix->ws_arena.as<int32_t>(), d_ids, d_scores);
-    HIPCHECK(ix, hipEventRecord(ix->ev[4], stream));
+    if (ix->profiling) HIPCHECK(ix, hipEventRecord(ix->ev[4], stream));
     launch_rerank(ix->cfg.dtype, ix->cfg.metric, rp, nq, stream);
-    HIPCHECK(ix, hipEventRecord(ix->ev[5], stream));
+    if (ix->profiling) HIPCHECK(ix, hipEventRecord(ix->ev[5], stream));
     HIPCHECK(ix, hipGetLastError());
     ix->last_path = 0;
     return DPF_OK;
@@ -1300,11 +1302,11 @@ extern "C" int dpf_get_stats(dpf_index *ix, dpf_stats *out)
         ix->st.last_forwarded = ix->st.last_unique_candidates;
         ix->st.last_unique_candidates = 0;          // the sets are not materialised on this path
         float t = 0, t2 = 0;
-        if (hipEventElapsedTime(&t, ix->ev_scan[0], ix->ev_scan[1]) == hipSuccess &&
+        if (ix->last_timed && hipEventElapsedTime(&t, ix->ev_scan[0], ix->ev_scan[1]) == hipSuccess &&
             hipEventElapsedTime(&t2, ix->ev_scan[2], ix->ev_scan[3]) == hipSuccess) ix->st.last_ms_scan = t + t2;
         ix->st.last_scan_launches = ix->scan_launches;
     }
-    if (ix->profiling && ix->last_valid) {
+    if (ix->last_timed && ix->last_valid) {
         float ms = 0;
         ix->st.last_ms_dedupe = 0;
         if (hipEventElapsedTime(&ms, ix->ev[0], ix->ev[1]) == hipSuccess) ix->st.last_ms_hash = ms;
@@ -1321,6 +1323,7 @@ extern "C" int dpf_last_rerank_profile(dpf_index *ix, double *ms, int64_t *algor
 {
     if (!ix) return DPF_EINVAL;
     if (!ix->last_valid || ix->last_k <= 0) return fail(ix, DPF_EINVAL, "dpf_last_rerank_profile: no top-k batch has run");
+    if (!ix->last_timed) return fail(ix, DPF_EINVAL, "dpf_last_rerank_profile: the last batch ran without dpf_set_profiling(1)");
     HIPCHECK(ix, hipSetDevice(ix->cfg.device));
     HIPCHECK(ix, hipEventSynchronize(ix->ev[5]));
     float t = 0;

@@ -217,6 +217,7 @@ def test_device_entry_point_matches_host_entry_point():
     di = torch.empty((33, 10), dtype=torch.int32, device=dev)
     ds = torch.empty((33, 10), dtype=torch.float64, device=dev)
     s = torch.cuda.Stream()
+    gpu.set_profiling(True)
     with torch.cuda.stream(s):
         gpu.query_topk_device(dqid.data_ptr(), dq.data_ptr(), 33, 1, 10, di.data_ptr(), ds.data_ptr(), s.cuda_stream)
     s.synchronize()
