@@ -627,3 +627,41 @@ def test_overflowed_queries_take_the_gather_path_alone(monkeypatch, metric, with
             assert fast.stats()["last_raw_candidates"] == st["last_raw_candidates"]
         fast.close()
     assert seen_partial
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(24))
+def test_random_configurations(seed):
+    # a seeded draw over the configuration space: hash family, index transform, trie geometry, overflow
+    # threshold, dimension, metric, k, search steps; scan path == gather path (bit for bit) == oracle
+    rng = np.random.RandomState(1000 + seed)
+    family = ["angle", "pStable"][rng.randint(2)]
+    toi = ["original", "sampling", "continueBitsCount"][rng.randint(3)] if family == "angle" else "original"
+    dns, bb = [(32, 28), (128, 28), (64, 30), (32, 30)][rng.randint(4)]
+    pb = int(rng.randint(0, 4))
+    B = int([3, 17, 60, 500][rng.randint(4)])
+    dim = int([8, 33, 64, 100, 130, 256][rng.randint(6)])
+    metric = ["l2", "dot"][rng.randint(2)]
+    k = int([1, 5, 10, 33][rng.randint(4)])
+    n, nq = int(rng.randint(1500, 6000)), int(rng.randint(5, 120))
+    kw = dict(table_num=int(rng.randint(1, 4)), permutation_num=1, pstable_w=3) if family == "pStable" else \
+        dict(table_num=int(rng.randint(1, 3)), permutation_num=int(rng.randint(1, 4)))
+    params, X, Q, pick = make_problem(n=n, nq=nq, dim=dim, family=family, type_of_index=toi, partition_bits=pb,
+                                      dir_node_size=dns, bucket_bits=bb, bucket_overflow=B, n_clusters=int(rng.randint(2, 40)),
+                                      seed=50 + seed, **kw)
+    fast = DpfIndex(params, metric=metric, top_k=k)
+    slow = DpfIndex(dict(params, flags=2), metric=metric, top_k=k)
+    fast.fit(X)
+    slow.fit(X)
+    orc = O.OracleIndex(params)
+    orc.fit(X.astype(np.float64))
+    Q64 = Q.astype(np.float64)
+    steps = int(rng.randint(0, pb + 1))
+    fi, fs = fast.query_topk(pick, Q, steps=steps, k=k)
+    assert fast.stats()["last_path"] == 1
+    si, ss = slow.query_topk(pick, Q, steps=steps, k=k)
+    assert np.array_equal(fi, si) and np.array_equal(fs, ss, equal_nan=True)
+    off, ids = orc.query_batch(pick, Q64, steps=steps)
+    assert_same_sets(fast.query_batch(pick, Q, steps=steps), (off, ids))
+    want = orc.topk(Q64, off, ids, k=k, metric=metric)
+    assert_topk_equal(fi, fs, want[0], want[1])
