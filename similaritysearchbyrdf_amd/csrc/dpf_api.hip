@@ -833,10 +833,13 @@ static void fill_rerank_params(dpf_index *ix, RerankParams &rp, const void *d_Qp
     rp.out_ids = d_ids; rp.out_scores = d_scores;
 }
 
-// ws_flag: 16 bytes of flags ([0] overflowed lists, [1] truncated bucket lists, [2] longest forward list), then the
-// ticket counters of the two scan launches (each counter on a 128-byte line of its own)
+// ws_flag: 16 bytes of flags ([0] overflowed lists, [1] truncated bucket lists, [2] longest forward list), the two
+// scan totals (incidences, units) as int64 at byte 16, and from byte 128 the ticket counters of the two scan
+// launches (each counter on a 128-byte line of its own)
 static const int TICKET_COUNTERS = 16;
-static const size_t FLAG_BYTES = 16 + 2 * (size_t)TICKET_COUNTERS * 128;
+static const size_t FLAG_BYTES = 128 + 2 * (size_t)TICKET_COUNTERS * 128;
+// the per-query forward counts sit behind them, so that one memset clears everything a batch starts from
+static int32_t *emit_cnt_of(const dpf_index *ix) { return (int32_t *)((char *)ix->ws_flag.p + FLAG_BYTES); }
 static const int32_t SEED_CAP = getenv("DPF_SEED_CAP") ? atoi(getenv("DPF_SEED_CAP")) : 256;     // seed sample per query
 // Forwarded candidates a query's list holds before the gather path answers the query instead.  The
 // handle starts at 8192 and doubles the lists (up to 65536) after a batch in which a list overflowed;
@@ -872,16 +875,14 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     HIPCHECK(ix, ix->ws_seed_ids.ensure((size_t)nq * k * 4));
     HIPCHECK(ix, ix->ws_seed_scores.ensure((size_t)nq * k * 8));
     HIPCHECK(ix, ix->ws_emit.ensure((size_t)nq * EMIT_CAP * 4));
-    HIPCHECK(ix, ix->ws_emit_cnt.ensure((size_t)nq * 4));
-    HIPCHECK(ix, ix->ws_flag.ensure(FLAG_BYTES));
+    HIPCHECK(ix, ix->ws_flag.ensure(FLAG_BYTES + (size_t)nq * 4));
     HIPCHECK(ix, ix->ws_tau.ensure((size_t)nq * 4));
 
     if (ix->profiling) HIPCHECK(ix, hipEventRecord(ix->ev[0], stream));
     launch_hash(ix->cfg.dtype, qpad, qstride, nq, ix->hp, ix->ws_hashes.as<int32_t>(), ix->ws_parts.as<int32_t>(), stream);
     if (ix->profiling) HIPCHECK(ix, hipEventRecord(ix->ev[1], stream));
     HIPCHECK(ix, hipMemsetAsync(ix->ws_lq_cnt.p, 0, (size_t)(nl + 1) * 4, stream));
-    HIPCHECK(ix, hipMemsetAsync(ix->ws_emit_cnt.p, 0, (size_t)nq * 4, stream));
-    HIPCHECK(ix, hipMemsetAsync(ix->ws_flag.p, 0, FLAG_BYTES, stream));
+    HIPCHECK(ix, hipMemsetAsync(ix->ws_flag.p, 0, FLAG_BYTES + (size_t)nq * 4, stream));
     ProbeParams pp;
     fill_probe_params(ix, pp, d_qids, steps);
     pp.lq_cnt = ix->ws_lq_cnt.as<uint32_t>();
@@ -900,17 +901,13 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
         pp.q_leaf_overflow = ix->ws_flag.as<int32_t>() + 1;
     }
     launch_probe(0, pp, nq, stream);
-    launch_scan_i32(ix->ws_lq_cnt.as<int32_t>(), nl, ix->ws_lq_off.as<int64_t>(), stream);
-    HIPCHECK(ix, ix->ws_leaf_units.ensure((size_t)(nl + 1) * 4));
     HIPCHECK(ix, ix->ws_unit_off.ensure((size_t)(nl + 2) * 8));
-    launch_unit_count(ix->ws_lq_cnt.as<uint32_t>(), ix->d_leaf_tile0.as<uint32_t>(), nl, ix->ws_leaf_units.as<int32_t>(),
-                      ix->ws_unit_off.as<int64_t>(), stream);
-    HIPCHECK(ix, hipMemcpyAsync(ix->pinned + 2, ix->ws_unit_off.as<int64_t>() + nl, 8, hipMemcpyDeviceToHost, stream));
-    HIPCHECK(ix, hipMemcpyAsync(ix->pinned, ix->ws_lq_off.as<int64_t>() + nl, 8, hipMemcpyDeviceToHost, stream));
-    HIPCHECK(ix, hipMemcpyAsync(ix->pinned + 3, pp.q_leaf_overflow, 4, hipMemcpyDeviceToHost, stream));
+    launch_bucket_scans(ix->ws_lq_cnt.as<uint32_t>(), ix->d_leaf_tile0.as<uint32_t>(), nl, ix->ws_lq_off.as<int64_t>(),
+                        ix->ws_unit_off.as<int64_t>(), (int64_t *)((char *)ix->ws_flag.p + 16), stream);
+    HIPCHECK(ix, hipMemcpyAsync(ix->pinned, ix->ws_flag.p, 32, hipMemcpyDeviceToHost, stream));   // flags + the two totals
     HIPCHECK(ix, hipStreamSynchronize(stream));
-    const int64_t pairs = ix->pinned[0], nunits = ix->pinned[2];
-    const bool lists_truncated = (int32_t)(ix->pinned[3] & 0xffffffff) != 0;
+    const int64_t pairs = ix->pinned[2], nunits = ix->pinned[3];
+    const bool lists_truncated = (int32_t)((uint64_t)ix->pinned[0] >> 32) != 0;
     // unit descriptors index leaf_queries[] and the unit list with 32 bits
     if (pairs >= (int64_t)0xffffffffll || nunits >= (int64_t)0xffffffffll) return DPF_OK;
     if (getenv("DPF_DEBUG")) {
@@ -996,14 +993,14 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     lp.tau = ix->ws_tau.as<int32_t>();
     lp.k = k;
     lp.emit = ix->ws_emit.as<int32_t>(); lp.emit_v = ix->ws_emit_v.as<float>();
-    lp.emit_cnt = ix->ws_emit_cnt.as<int32_t>(); lp.emit_cap = EMIT_CAP;
+    lp.emit_cnt = emit_cnt_of(ix); lp.emit_cap = EMIT_CAP;
     lp.debug = getenv("DPF_LS_DEBUG") ? atoi(getenv("DPF_LS_DEBUG")) : 0;
     lp.Q16 = ix->ws_q16.as<uint16_t>(); lp.base16 = ix->d_base16.as<uint16_t>();
     lp.slot_norm = ix->d_slot_norm.as<float>(); lp.qc = (const float4 *)ix->ws_qc.p;
     lp.units = (const uint4 *)ix->ws_units.p;
     lp.num_cus = ix->num_cus; lp.ks = ix->ks16;
     lp.num_counters = TICKET_COUNTERS;
-    lp.tickets = (unsigned int *)((char *)ix->ws_flag.p + 16);
+    lp.tickets = (unsigned int *)((char *)ix->ws_flag.p + 128);
     // a first slice of the units, then thresholds refined from what it forwarded, then the rest
     static const int first_permille = getenv("DPF_FIRST_PASS") ? atoi(getenv("DPF_FIRST_PASS")) : 100;
     const int64_t n_first = std::min<int64_t>(nunits, nunits * first_permille / 1000);
@@ -1022,13 +1019,13 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     launch_leafscan(ix->cfg.metric, lp, stream);
     if (ix->profiling) HIPCHECK(ix, hipEventRecord(ix->ev_scan[3], stream));
     HIPCHECK(ix, ix->ws_ovf.ensure((size_t)nq * 4));
-    launch_overflow_list(ix->ws_emit_cnt.as<int32_t>(), nq, EMIT_CAP, ix->ws_flag.as<int32_t>(), ix->ws_ovf.as<int32_t>(), stream);
+    launch_overflow_list(emit_cnt_of(ix), nq, EMIT_CAP, ix->ws_flag.as<int32_t>(), ix->ws_ovf.as<int32_t>(), stream);
     HIPCHECK(ix, hipMemcpyAsync(ix->pinned + 4, ix->ws_flag.p, 16, hipMemcpyDeviceToHost, stream));
     HIPCHECK(ix, hipStreamSynchronize(stream));
     ix->st.last_pairs = pairs;
     if (getenv("DPF_DEBUG")) {
         std::vector<int32_t> c((size_t)nq);
-        HIPCHECK(ix, hipMemcpy(c.data(), ix->ws_emit_cnt.p, (size_t)nq * 4, hipMemcpyDeviceToHost));
+        HIPCHECK(ix, hipMemcpy(c.data(), (void *)emit_cnt_of(ix), (size_t)nq * 4, hipMemcpyDeviceToHost));
         std::sort(c.begin(), c.end());
         fprintf(stderr, "[dpf] forwarded per query: median %d p90 %d p99 %d max %d (cap %d)\n", c[c.size() / 2],
                 c[c.size() * 9 / 10], c[c.size() * 99 / 100], c.back(), EMIT_CAP);
@@ -1045,10 +1042,10 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     const bool dedupe = unique_lists_lds(std::min(longest, EMIT_CAP)) <= 128 * 1024;   // the table of the longest list fits LDS
     if (dedupe) {
         HIPCHECK(ix, ix->ws_emit_ucnt.ensure((size_t)nq * 4));
-        launch_unique_lists(ix->ws_emit.as<int32_t>(), ix->ws_emit_cnt.as<int32_t>(), EMIT_CAP, longest, ix->ws_emit_ucnt.as<int32_t>(), nq,
+        launch_unique_lists(ix->ws_emit.as<int32_t>(), emit_cnt_of(ix), EMIT_CAP, longest, ix->ws_emit_ucnt.as<int32_t>(), nq,
                             stream);
     }
-    fill_rerank_params(ix, rp, qpad, k, nullptr, dedupe ? ix->ws_emit_ucnt.as<int32_t>() : ix->ws_emit_cnt.as<int32_t>(),
+    fill_rerank_params(ix, rp, qpad, k, nullptr, dedupe ? ix->ws_emit_ucnt.as<int32_t>() : emit_cnt_of(ix),
                        ix->ws_emit.as<int32_t>(), d_ids, d_scores);
     rp.cand_stride = EMIT_CAP;
     if (ix->profiling) HIPCHECK(ix, hipEventRecord(ix->ev[4], stream));
@@ -1278,7 +1275,7 @@ static int last_totals(dpf_index *ix, int64_t *raw_total, int64_t *uniq_total)
     std::vector<int32_t> cnt((size_t)ix->last_nq);
     HIPCHECK(ix, hipMemcpy(raw.data(), ix->ws_raw.p, raw.size() * 8, hipMemcpyDeviceToHost));
     // gather path: per-query set sizes; bucket-major path: candidates forwarded to the exact rerank
-    HIPCHECK(ix, hipMemcpy(cnt.data(), ix->last_path == 1 ? ix->ws_emit_cnt.p : ix->ws_cnt.p, cnt.size() * 4, hipMemcpyDeviceToHost));
+    HIPCHECK(ix, hipMemcpy(cnt.data(), ix->last_path == 1 ? (void *)emit_cnt_of(ix) : ix->ws_cnt.p, cnt.size() * 4, hipMemcpyDeviceToHost));
     for (auto v : raw) *raw_total += (int64_t)v;
     for (auto v : cnt) *uniq_total += v;
     return DPF_OK;

@@ -113,8 +113,8 @@ size_t hash_shmem_bytes(const HashParams &p);
 void launch_probe(int mode, const ProbeParams &p, int64_t nq, hipStream_t stream);
 void launch_fill_lists(const ProbeParams &p, int64_t nq, hipStream_t stream);
 void launch_leafscan(int metric, const LeafScanParams &p, hipStream_t stream);
-void launch_unit_count(const uint32_t *lq_cnt, const uint32_t *leaf_tile0, int64_t nl, int32_t *leaf_units, int64_t *unit_off,
-                       hipStream_t stream);
+void launch_bucket_scans(const uint32_t *lq_cnt, const uint32_t *leaf_tile0, int64_t nl, int64_t *lq_off, int64_t *unit_off,
+                         int64_t *totals, hipStream_t stream);
 void launch_units(const uint32_t *lq_cnt, const int64_t *lq_off, const uint32_t *leaf_tile0, const uint4 *tiles, int64_t ntiles,
                   const int64_t *unit_off, uint4 *units, hipStream_t stream);
 void launch_tile_maxnorm(uint4 *tiles, int64_t ntiles, const int32_t *ids, const float *norms, const float *errs, int64_t row_begin,

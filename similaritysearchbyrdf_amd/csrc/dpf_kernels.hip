@@ -1077,13 +1077,97 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 static constexpr uint32_t UNIT_QUERIES = 128;
 __device__ inline uint32_t units_of_leaf(uint32_t cnt, uint32_t ntl) { return cnt ? ntl * ((cnt + UNIT_QUERIES - 1u) / UNIT_QUERIES) : 0u; }
 
-// per-bucket unit counts; their exclusive scan places each bucket's units (bucket order, so the
-// unit list is the same for the same batch on every run)
-__global__ __launch_bounds__(256) void k_unit_count(const uint32_t *__restrict__ lq_cnt, const uint32_t *__restrict__ leaf_tile0,
-                                                    int64_t nl, int32_t *__restrict__ leaf_units)
+// The two exclusive scans the batch needs over the buckets, in one set of launches: lq_off[] over the
+// (query, bucket) incidence counts and unit_off[] over the per-bucket unit counts (bucket order, so the
+// unit list is the same for the same batch on every run); totals[0..1] = the two sums.
+__device__ __forceinline__ void scan2_inputs(const uint32_t *lq_cnt, const uint32_t *leaf_tile0, int64_t i, int64_t n, int64_t &a, int64_t &b)
 {
-    const int64_t l = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (l < nl) leaf_units[l] = (int32_t)units_of_leaf(lq_cnt[l], leaf_tile0[l + 1] - leaf_tile0[l]);
+    a = 0; b = 0;
+    if (i < n) {
+        const uint32_t c = lq_cnt[i];
+        a = c;
+        b = units_of_leaf(c, leaf_tile0[i + 1] - leaf_tile0[i]);
+    }
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan2_sums(const uint32_t *__restrict__ lq_cnt, const uint32_t *__restrict__ leaf_tile0,
+                                                             int64_t n, int64_t *__restrict__ offa, int64_t *__restrict__ offb)
+{
+    __shared__ int64_t sh[4];
+    const int64_t t0 = (int64_t)blockIdx.x * SCAN_TILE;
+    int64_t sa = 0, sb = 0;
+    for (int j = 0; j < SCAN_PER; j++) {
+        int64_t a, b;
+        scan2_inputs(lq_cnt, leaf_tile0, t0 + j * SCAN_THREADS + threadIdx.x, n, a, b);
+        sa += a; sb += b;
+    }
+    sa = block_sum256(sa, sh);
+    __syncthreads();
+    sb = block_sum256(sb, sh);
+    if (threadIdx.x == 0) { offa[t0] = sa; offb[t0] = sb; }
+}
+
+__global__ __launch_bounds__(1024) void k_scan2_tiles(int64_t n, int64_t ntiles, int64_t *__restrict__ offa, int64_t *__restrict__ offb,
+                                                      int64_t *__restrict__ totals)
+{
+    __shared__ int64_t part[1024];
+    const int tid = threadIdx.x;
+    const int64_t per = (ntiles + 1023) / 1024;
+    const int64_t b = tid * per, e = (b + per < ntiles) ? b + per : ntiles;
+    for (int which = 0; which < 2; which++) {
+        int64_t *off = which ? offb : offa;
+        int64_t s = 0;
+        for (int64_t i = b; i < e; i++) s += off[i * SCAN_TILE];
+        __syncthreads();
+        part[tid] = s;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            int64_t v = tid >= o ? part[tid - o] : 0;
+            __syncthreads();
+            part[tid] += v;
+            __syncthreads();
+        }
+        int64_t run = part[tid] - s;
+        for (int64_t i = b; i < e; i++) { const int64_t v = off[i * SCAN_TILE]; off[i * SCAN_TILE] = run; run += v; }
+        if (tid == 1023) { off[n] = part[1023]; totals[which] = part[1023]; }
+    }
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan2_apply(const uint32_t *__restrict__ lq_cnt, const uint32_t *__restrict__ leaf_tile0,
+                                                              int64_t n, int64_t *__restrict__ offa, int64_t *__restrict__ offb)
+{
+    __shared__ int64_t wsa[4], wsb[4];
+    const int64_t t0 = (int64_t)blockIdx.x * SCAN_TILE;
+    const int64_t basea = offa[t0], baseb = offb[t0];
+    // thread t owns inputs t*SCAN_PER .. t*SCAN_PER+SCAN_PER-1 of the tile
+    int64_t va[SCAN_PER], vb[SCAN_PER], sa = 0, sb = 0;
+    const int64_t i0 = t0 + (int64_t)threadIdx.x * SCAN_PER;
+#pragma unroll
+    for (int j = 0; j < SCAN_PER; j++) { scan2_inputs(lq_cnt, leaf_tile0, i0 + j, n, va[j], vb[j]); sa += va[j]; sb += vb[j]; }
+    int64_t ia = sa, ib = sb;                         // inclusive scans over the wave
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int o = 1; o < 64; o <<= 1) {
+        const int64_t ua = __shfl_up(ia, o), ub = __shfl_up(ib, o);
+        if (lane >= o) { ia += ua; ib += ub; }
+    }
+    if (lane == 63) { wsa[w] = ia; wsb[w] = ib; }
+    __syncthreads();                                  // also orders the reads of off[t0] before the writes below
+    int64_t ra = basea + ia - sa, rb = baseb + ib - sb;
+    for (int u = 0; u < w; u++) { ra += wsa[u]; rb += wsb[u]; }
+#pragma unroll
+    for (int j = 0; j < SCAN_PER; j++) {
+        if (i0 + j < n) { offa[i0 + j] = ra; offb[i0 + j] = rb; }
+        ra += va[j]; rb += vb[j];
+    }
+}
+
+void launch_bucket_scans(const uint32_t *lq_cnt, const uint32_t *leaf_tile0, int64_t nl, int64_t *lq_off, int64_t *unit_off,
+                         int64_t *totals, hipStream_t stream)
+{
+    const int64_t ntiles = (nl + SCAN_TILE - 1) / SCAN_TILE;
+    if (ntiles > 0) hipLaunchKernelGGL(k_scan2_sums, dim3((unsigned)ntiles), dim3(SCAN_THREADS), 0, stream, lq_cnt, leaf_tile0, nl, lq_off, unit_off);
+    hipLaunchKernelGGL(k_scan2_tiles, dim3(1), dim3(1024), 0, stream, nl, ntiles, lq_off, unit_off, totals);
+    if (ntiles > 0) hipLaunchKernelGGL(k_scan2_apply, dim3((unsigned)ntiles), dim3(SCAN_THREADS), 0, stream, lq_cnt, leaf_tile0, nl, lq_off, unit_off);
 }
 
 // one thread per tile (a long bucket has thousands of them)
@@ -1133,13 +1217,6 @@ __global__ __launch_bounds__(256) void k_tile_maxnorm(uint4 *__restrict__ tiles,
     tiles[t] = td;
 }
 
-// unit_off[0..nl] = exclusive scan of the per-bucket unit counts (leaf_units is scratch, nl ints)
-void launch_unit_count(const uint32_t *lq_cnt, const uint32_t *leaf_tile0, int64_t nl, int32_t *leaf_units, int64_t *unit_off,
-                       hipStream_t stream)
-{
-    if (nl > 0) hipLaunchKernelGGL(k_unit_count, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, stream, lq_cnt, leaf_tile0, nl, leaf_units);
-    launch_scan_i32(leaf_units, nl, unit_off, stream);
-}
 void launch_units(const uint32_t *lq_cnt, const int64_t *lq_off, const uint32_t *leaf_tile0, const uint4 *tiles, int64_t ntiles,
                   const int64_t *unit_off, uint4 *units, hipStream_t stream)
 {
