@@ -235,8 +235,8 @@ def main():
 
     gather = None
     if rank == 0 and world == 1 and st["last_path"] == 1:
-        # the per-query gather rerank on the same batch (untimed): the kernel SURVEY's rerank roofline
-        # is defined on, and the source of the de-duplicated candidate count
+        # the per-query gather rerank on the same batch (untimed): its bytes are the classic rerank roofline
+        # (every de-duplicated candidate row once per query), and it yields the de-duplicated candidate count
         from similaritysearchbyrdf_amd._lib import DpfIndex
         gi = DpfIndex(dict(params, flags=2), metric=args.metric, top_k=k, dtype=np.float32, device=local)
         gi.fit(X)
