@@ -106,6 +106,9 @@ typedef struct dpf_stats {
     double  fit_ms_total;        /* ... whole call                                                   */
     int64_t last_overflowed;     /* queries of the last bucket-major batch whose forward list overflowed and
                                     that were answered by the gather path instead */
+    int64_t last_sizes_carried;  /* last bucket-major batch: 0 = the host read the batch's list sizes before
+                                    filling the lists, 1 = it did not wait for them (buffers sized by earlier
+                                    batches), 2 = as 1, but the batch outgrew the buffers and was run again */
 } dpf_stats;
 
 typedef struct dpf_index dpf_index;

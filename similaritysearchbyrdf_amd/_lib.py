@@ -36,7 +36,7 @@ class DpfStats(C.Structure):
                                   "last_ms_scan")] + [
         (n, C.c_int64) for n in ("last_path", "last_pairs", "last_forwarded", "last_scan_launches", "snapshot_bytes",
                                  "base_bytes")] + [
-        (n, C.c_double) for n in ("fit_ms_hash", "fit_ms_forest", "fit_ms_total")] + [("last_overflowed", C.c_int64)]
+        (n, C.c_double) for n in ("fit_ms_hash", "fit_ms_forest", "fit_ms_total")] + [("last_overflowed", C.c_int64), ("last_sizes_carried", C.c_int64)]
 
 
 EXPORTS = (

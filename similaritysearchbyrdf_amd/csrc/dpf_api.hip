@@ -112,6 +112,7 @@ struct dpf_index {
     int scan_launches = 0;
     unsigned long long *d_short_hash = nullptr;
     int64_t *pinned = nullptr;                        // host-pinned scratch (8 x int64)
+    bool sizes_carried = false;                       // a bucket-major batch has sized leaf_queries[] / units[] already
     hipEvent_t ev[6]{};
     int last_path = 0;
     bool profiling = false;
@@ -867,7 +868,10 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     HIPCHECK(ix, ix->ws_parts.ensure((size_t)nq * L * 4));
     HIPCHECK(ix, ix->ws_raw.ensure((size_t)nq * 8));
     HIPCHECK(ix, ix->ws_bound.ensure((size_t)nq * 8));
-    HIPCHECK(ix, ix->ws_lq_cnt.ensure((size_t)(nl + 1) * 4));
+    // (cleared sizes are whole 256-byte runs: one fill kernel each instead of a body and a tail)
+    const size_t lq_cnt_bytes = ((size_t)(nl + 1) * 4 + 255) & ~(size_t)255;
+    const size_t flag_bytes = (FLAG_BYTES + (size_t)nq * 4 + 255) & ~(size_t)255;
+    HIPCHECK(ix, ix->ws_lq_cnt.ensure(lq_cnt_bytes));
     HIPCHECK(ix, ix->ws_lq_cursor.ensure((size_t)(nl + 1) * 4));
     HIPCHECK(ix, ix->ws_lq_off.ensure((size_t)(nl + 2) * 8));
     HIPCHECK(ix, ix->ws_seed_cand.ensure((size_t)nq * SEED_CAP * 4));
@@ -875,14 +879,14 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     HIPCHECK(ix, ix->ws_seed_ids.ensure((size_t)nq * k * 4));
     HIPCHECK(ix, ix->ws_seed_scores.ensure((size_t)nq * k * 8));
     HIPCHECK(ix, ix->ws_emit.ensure((size_t)nq * EMIT_CAP * 4));
-    HIPCHECK(ix, ix->ws_flag.ensure(FLAG_BYTES + (size_t)nq * 4));
+    HIPCHECK(ix, ix->ws_flag.ensure(flag_bytes));
     HIPCHECK(ix, ix->ws_tau.ensure((size_t)nq * 4));
 
     if (ix->profiling) HIPCHECK(ix, hipEventRecord(ix->ev[0], stream));
     launch_hash(ix->cfg.dtype, qpad, qstride, nq, ix->hp, ix->ws_hashes.as<int32_t>(), ix->ws_parts.as<int32_t>(), stream);
     if (ix->profiling) HIPCHECK(ix, hipEventRecord(ix->ev[1], stream));
-    HIPCHECK(ix, hipMemsetAsync(ix->ws_lq_cnt.p, 0, (size_t)(nl + 1) * 4, stream));
-    HIPCHECK(ix, hipMemsetAsync(ix->ws_flag.p, 0, FLAG_BYTES + (size_t)nq * 4, stream));
+    HIPCHECK(ix, hipMemsetAsync(ix->ws_lq_cnt.p, 0, lq_cnt_bytes, stream));
+    HIPCHECK(ix, hipMemsetAsync(ix->ws_flag.p, 0, flag_bytes, stream));
     ProbeParams pp;
     fill_probe_params(ix, pp, d_qids, steps);
     pp.lq_cnt = ix->ws_lq_cnt.as<uint32_t>();
@@ -902,14 +906,28 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     }
     launch_probe(0, pp, nq, stream);
     HIPCHECK(ix, ix->ws_unit_off.ensure((size_t)(nl + 2) * 8));
+    // The two totals of the batch (bucket incidences, work units) size leaf_queries[] and units[].  The first
+    // batch of a handle reads them back here; later batches do not wait: the kernels behind this point take the
+    // totals from device memory, the buffers keep the headroom earlier batches left them, and a batch that
+    // outgrows them (or truncated a bucket list) raises a flag, writes nothing and is run again the slow way.
+    static const bool no_carry = getenv("DPF_SYNC_SIZES") != nullptr;
+    const bool carried = ix->sizes_carried && !no_carry && !getenv("DPF_DEBUG");
+    const int64_t cap_pairs = std::min<int64_t>((int64_t)(ix->ws_leaf_queries.cap / 4), 0xfffffffell);
+    const int64_t cap_units = std::min<int64_t>((int64_t)(ix->ws_units.cap / 16), 0xfffffffell);
+    int32_t *const flags = ix->ws_flag.as<int32_t>();
+    int64_t *const d_totals = (int64_t *)((char *)ix->ws_flag.p + 16);
     launch_bucket_scans(ix->ws_lq_cnt.as<uint32_t>(), ix->d_leaf_tile0.as<uint32_t>(), nl, ix->ws_lq_off.as<int64_t>(),
-                        ix->ws_unit_off.as<int64_t>(), (int64_t *)((char *)ix->ws_flag.p + 16), stream);
-    HIPCHECK(ix, hipMemcpyAsync(ix->pinned, ix->ws_flag.p, 32, hipMemcpyDeviceToHost, stream));   // flags + the two totals
-    HIPCHECK(ix, hipStreamSynchronize(stream));
-    const int64_t pairs = ix->pinned[2], nunits = ix->pinned[3];
-    const bool lists_truncated = (int32_t)((uint64_t)ix->pinned[0] >> 32) != 0;
-    // unit descriptors index leaf_queries[] and the unit list with 32 bits
-    if (pairs >= (int64_t)0xffffffffll || nunits >= (int64_t)0xffffffffll) return DPF_OK;
+                        ix->ws_unit_off.as<int64_t>(), d_totals, carried, cap_pairs, cap_units, flags, stream);
+    int64_t pairs = 0, nunits = 0;
+    bool lists_truncated = false;
+    if (!carried) {
+        HIPCHECK(ix, hipMemcpyAsync(ix->pinned, ix->ws_flag.p, 32, hipMemcpyDeviceToHost, stream));   // flags + the two totals
+        HIPCHECK(ix, hipStreamSynchronize(stream));
+        pairs = ix->pinned[2]; nunits = ix->pinned[3];
+        lists_truncated = (int32_t)((uint64_t)ix->pinned[0] >> 32) != 0;
+        // unit descriptors index leaf_queries[] and the unit list with 32 bits
+        if (pairs >= (int64_t)0xffffffffll || nunits >= (int64_t)0xffffffffll) return DPF_OK;
+    }
     if (getenv("DPF_DEBUG")) {
         std::vector<uint32_t> c((size_t)nl);
         HIPCHECK(ix, hipMemcpy(c.data(), ix->ws_lq_cnt.p, (size_t)nl * 4, hipMemcpyDeviceToHost));
@@ -949,7 +967,8 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
                 (long long)nl, touched, (long long)pairs, srt[srt.size() / 2], srt[srt.size() * 9 / 10],
                 srt[srt.size() * 99 / 100], srt[srt.size() * 999 / 1000], srt.back());
     }
-    HIPCHECK(ix, ix->ws_leaf_queries.ensure((size_t)std::max<int64_t>(pairs, 1) * 4));
+    if (!carried) HIPCHECK(ix, ix->ws_leaf_queries.ensure((size_t)std::max<int64_t>(pairs + pairs / 2, 1024) * 4));
+    pp.abort = carried ? flags + 3 : nullptr;
     pp.lq_off = ix->ws_lq_off.as<int64_t>();
     pp.lq_cursor = ix->ws_lq_cursor.as<uint32_t>();
     pp.leaf_queries = ix->ws_leaf_queries.as<int32_t>();
@@ -981,9 +1000,10 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
                        ix->ws_q16n.as<float>(), ix->ws_q16e.as<float>(), stream);
     launch_tau(ix->cfg.metric, ix->ws_seed_scores.as<double>(), ix->ws_seed_ids.as<int32_t>(), k, nq, ix->ws_q16n.as<float>(),
                ix->ws_q16e.as<float>(), d_qids, ix->ks16, ix->ws_tau.as<int32_t>(), (float4 *)ix->ws_qc.p, stream);
-    HIPCHECK(ix, ix->ws_units.ensure((size_t)std::max<int64_t>(nunits, 1) * 16));
+    if (!carried) HIPCHECK(ix, ix->ws_units.ensure((size_t)std::max<int64_t>(nunits + nunits / 2, 1024) * 16));
     launch_units(ix->ws_lq_cnt.as<uint32_t>(), ix->ws_lq_off.as<int64_t>(), ix->d_leaf_tile0.as<uint32_t>(),
-                 (const uint4 *)ix->d_tiles.p, ix->nutiles, ix->ws_unit_off.as<int64_t>(), (uint4 *)ix->ws_units.p, stream);
+                 (const uint4 *)ix->d_tiles.p, ix->nutiles, ix->ws_unit_off.as<int64_t>(), (uint4 *)ix->ws_units.p,
+                 carried ? flags + 3 : nullptr, stream);
     HIPCHECK(ix, ix->ws_emit_v.ensure((size_t)nq * EMIT_CAP * 4));
     LeafScanParams lp;
     lp.ids = ix->d_ids.as<int32_t>();
@@ -1003,25 +1023,38 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     lp.tickets = (unsigned int *)((char *)ix->ws_flag.p + 128);
     // a first slice of the units, then thresholds refined from what it forwarded, then the rest
     static const int first_permille = getenv("DPF_FIRST_PASS") ? atoi(getenv("DPF_FIRST_PASS")) : 100;
-    const int64_t n_first = std::min<int64_t>(nunits, nunits * first_permille / 1000);
-    ix->scan_launches = 1;
+    int64_t n_first = std::min<int64_t>(nunits, nunits * first_permille / 1000);
+    if (carried) { lp.totals = d_totals; lp.abort = flags + 3; lp.first_permille = first_permille; }
+    lp.pass = 0;
     lp.unit_begin = 0; lp.unit_end = n_first;
     if (ix->profiling) HIPCHECK(ix, hipEventRecord(ix->ev_scan[0], stream));
     launch_leafscan(ix->cfg.metric, lp, stream);
     if (ix->profiling) HIPCHECK(ix, hipEventRecord(ix->ev_scan[1], stream));
-    if (n_first > 0) {
+    if (n_first > 0 || carried)
         launch_refine(ix->cfg.metric, lp.emit, lp.emit_v, lp.emit_cnt, EMIT_CAP, k, nq, ix->ws_q16e.as<float>(), lp.tau, stream);
-        ix->scan_launches = 2;
-    }
+    lp.pass = 1;
     lp.unit_begin = n_first; lp.unit_end = nunits;
     lp.tickets += TICKET_COUNTERS * 32;                   // the second launch's own counters
     if (ix->profiling) HIPCHECK(ix, hipEventRecord(ix->ev_scan[2], stream));
     launch_leafscan(ix->cfg.metric, lp, stream);
     if (ix->profiling) HIPCHECK(ix, hipEventRecord(ix->ev_scan[3], stream));
     HIPCHECK(ix, ix->ws_ovf.ensure((size_t)nq * 4));
-    launch_overflow_list(emit_cnt_of(ix), nq, EMIT_CAP, ix->ws_flag.as<int32_t>(), ix->ws_ovf.as<int32_t>(), stream);
-    HIPCHECK(ix, hipMemcpyAsync(ix->pinned + 4, ix->ws_flag.p, 16, hipMemcpyDeviceToHost, stream));
+    launch_overflow_list(emit_cnt_of(ix), nq, EMIT_CAP, flags, ix->ws_ovf.as<int32_t>(), stream);
+    HIPCHECK(ix, hipMemcpyAsync(ix->pinned + 4, ix->ws_flag.p, 32, hipMemcpyDeviceToHost, stream));
     HIPCHECK(ix, hipStreamSynchronize(stream));
+    if (carried) {
+        if ((int32_t)((uint64_t)ix->pinned[5] >> 32) != 0) {         // abandoned on the device: again, reading the sizes first
+            ix->sizes_carried = false;
+            const int rc = run_topk_bucket_major(ix, d_qids, qpad, qstride, nq, steps, k, d_ids, d_scores, stream, done);
+            ix->st.last_sizes_carried = 2;
+            return rc;
+        }
+        pairs = ix->pinned[6]; nunits = ix->pinned[7];
+        n_first = std::min<int64_t>(nunits, nunits * first_permille / 1000);
+    }
+    ix->st.last_sizes_carried = carried ? 1 : 0;
+    ix->sizes_carried = !lists_truncated;
+    ix->scan_launches = n_first > 0 ? 2 : 1;
     ix->st.last_pairs = pairs;
     if (getenv("DPF_DEBUG")) {
         std::vector<int32_t> c((size_t)nq);

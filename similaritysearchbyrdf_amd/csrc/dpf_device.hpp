@@ -62,6 +62,7 @@ struct ProbeParams {
     int32_t *seed_cand;       // [nq][seed_cap] ids from table 0's buckets
     int32_t *seed_cnt;        // [nq]
     int32_t seed_cap;
+    const int32_t *abort = nullptr;   // k_fill_lists: when set and non-zero the batch is being abandoned, write nothing
 };
 
 // Bucket-major scan: every touched bucket's rows are loaded once and scored
@@ -84,7 +85,12 @@ struct LeafScanParams {
     const uint16_t *base16;
     const float *slot_norm;      // squared norms of the fp16 copies (fp32 sums), in bucket order beside ids[]
     const uint4 *units;          // work units of the batch, see k_units
-    int64_t unit_begin, unit_end; // the slice of units[] this launch works through
+    int64_t unit_begin, unit_end; // the slice of units[] this launch works through ...
+    // ... or, when the host has not read the batch's unit count (totals != nullptr): totals[1] units in all,
+    // pass 0 takes the first first_permille/1000 of them, pass 1 the rest; nothing when *abort is non-zero
+    const int64_t *totals = nullptr;
+    const int32_t *abort = nullptr;
+    int32_t first_permille = 0, pass = 0;
     int32_t num_cus;
     unsigned int *tickets;       // num_counters ticket counters of this launch, 32 words apart, zeroed
     int32_t num_counters;
@@ -113,10 +119,11 @@ size_t hash_shmem_bytes(const HashParams &p);
 void launch_probe(int mode, const ProbeParams &p, int64_t nq, hipStream_t stream);
 void launch_fill_lists(const ProbeParams &p, int64_t nq, hipStream_t stream);
 void launch_leafscan(int metric, const LeafScanParams &p, hipStream_t stream);
+// flags[1] != 0 (a truncated bucket list) or a total beyond its capacity sets flags[3] when `guarded`
 void launch_bucket_scans(const uint32_t *lq_cnt, const uint32_t *leaf_tile0, int64_t nl, int64_t *lq_off, int64_t *unit_off,
-                         int64_t *totals, hipStream_t stream);
+                         int64_t *totals, bool guarded, int64_t cap_pairs, int64_t cap_units, int32_t *flags, hipStream_t stream);
 void launch_units(const uint32_t *lq_cnt, const int64_t *lq_off, const uint32_t *leaf_tile0, const uint4 *tiles, int64_t ntiles,
-                  const int64_t *unit_off, uint4 *units, hipStream_t stream);
+                  const int64_t *unit_off, uint4 *units, const int32_t *abort, hipStream_t stream);
 void launch_tile_maxnorm(uint4 *tiles, int64_t ntiles, const int32_t *ids, const float *norms, const float *errs, int64_t row_begin,
                          int64_t row_end, float *slot_norms, hipStream_t stream);
 int leafscan_f16_steps(int dim);

@@ -537,6 +537,10 @@ __global__ __launch_bounds__(256) void k_fill_lists(ProbeParams p)
     __shared__ uint32_t s_own[256];
     const int64_t q = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (p.abort && *p.abort) {                            // the lists have no room for this batch: it is run again
+        if (tid == 0) p.seed_cnt[q] = 0;
+        return;
+    }
     const int n = min(p.q_leaf_cnt[q], p.q_leaf_cap);
     const int32_t qid = p.qids ? p.qids[q] : -1;
     if (tid == 0) { s_seed = 0; s_nown = 0; }
@@ -1108,7 +1112,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan2_sums(const uint32_t *__r
 }
 
 __global__ __launch_bounds__(1024) void k_scan2_tiles(int64_t n, int64_t ntiles, int64_t *__restrict__ offa, int64_t *__restrict__ offb,
-                                                      int64_t *__restrict__ totals)
+                                                      int64_t *__restrict__ totals, int guarded, int64_t cap_a, int64_t cap_b,
+                                                      int32_t *__restrict__ flags)
 {
     __shared__ int64_t part[1024];
     const int tid = threadIdx.x;
@@ -1129,7 +1134,12 @@ __global__ __launch_bounds__(1024) void k_scan2_tiles(int64_t n, int64_t ntiles,
         }
         int64_t run = part[tid] - s;
         for (int64_t i = b; i < e; i++) { const int64_t v = off[i * SCAN_TILE]; off[i * SCAN_TILE] = run; run += v; }
-        if (tid == 1023) { off[n] = part[1023]; totals[which] = part[1023]; }
+        if (tid == 1023) {
+            off[n] = part[1023];
+            totals[which] = part[1023];
+            // the kernels behind this one were launched for buffers of cap_a / cap_b entries
+            if (guarded && (part[1023] > (which ? cap_b : cap_a) || flags[1] != 0)) flags[3] = 1;
+        }
     }
 }
 
@@ -1162,21 +1172,23 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan2_apply(const uint32_t *__
 }
 
 void launch_bucket_scans(const uint32_t *lq_cnt, const uint32_t *leaf_tile0, int64_t nl, int64_t *lq_off, int64_t *unit_off,
-                         int64_t *totals, hipStream_t stream)
+                         int64_t *totals, bool guarded, int64_t cap_pairs, int64_t cap_units, int32_t *flags, hipStream_t stream)
 {
     const int64_t ntiles = (nl + SCAN_TILE - 1) / SCAN_TILE;
     if (ntiles > 0) hipLaunchKernelGGL(k_scan2_sums, dim3((unsigned)ntiles), dim3(SCAN_THREADS), 0, stream, lq_cnt, leaf_tile0, nl, lq_off, unit_off);
-    hipLaunchKernelGGL(k_scan2_tiles, dim3(1), dim3(1024), 0, stream, nl, ntiles, lq_off, unit_off, totals);
+    hipLaunchKernelGGL(k_scan2_tiles, dim3(1), dim3(1024), 0, stream, nl, ntiles, lq_off, unit_off, totals, guarded ? 1 : 0,
+                       cap_pairs, cap_units, flags);
     if (ntiles > 0) hipLaunchKernelGGL(k_scan2_apply, dim3((unsigned)ntiles), dim3(SCAN_THREADS), 0, stream, lq_cnt, leaf_tile0, nl, lq_off, unit_off);
 }
 
 // one thread per tile (a long bucket has thousands of them)
 __global__ __launch_bounds__(256) void k_units(const uint32_t *__restrict__ lq_cnt, const int64_t *__restrict__ lq_off,
                                                const uint32_t *__restrict__ leaf_tile0, const uint4 *__restrict__ tiles,
-                                               int64_t ntiles, const int64_t *__restrict__ unit_off, uint4 *__restrict__ units)
+                                               int64_t ntiles, const int64_t *__restrict__ unit_off, uint4 *__restrict__ units,
+                                               const int32_t *__restrict__ abort)
 {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= ntiles) return;
+    if (t >= ntiles || (abort && *abort)) return;
     const uint4 td = tiles[t];
     const uint32_t l = td.x, cnt = lq_cnt[l];
     if (cnt == 0) return;
@@ -1218,9 +1230,9 @@ __global__ __launch_bounds__(256) void k_tile_maxnorm(uint4 *__restrict__ tiles,
 }
 
 void launch_units(const uint32_t *lq_cnt, const int64_t *lq_off, const uint32_t *leaf_tile0, const uint4 *tiles, int64_t ntiles,
-                  const int64_t *unit_off, uint4 *units, hipStream_t stream)
+                  const int64_t *unit_off, uint4 *units, const int32_t *abort, hipStream_t stream)
 {
-    if (ntiles > 0) hipLaunchKernelGGL(k_units, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, stream, lq_cnt, lq_off, leaf_tile0, tiles, ntiles, unit_off, units);
+    if (ntiles > 0) hipLaunchKernelGGL(k_units, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, stream, lq_cnt, lq_off, leaf_tile0, tiles, ntiles, unit_off, units, abort);
 }
 void launch_tile_maxnorm(uint4 *tiles, int64_t ntiles, const int32_t *ids, const float *norms, const float *errs, int64_t row_begin,
                          int64_t row_end, float *slot_norms, hipStream_t stream)
@@ -1455,13 +1467,19 @@ __global__ __launch_bounds__(256, ls16_waves(KS, RB)) void k_leafscan_f16(LeafSc
     // blockIdx % NC == c.  A wave's first three tickets are fixed (its place among the counter's waves, plus
     // one and two rounds), later ones come from atomicAdd, fetched one unit ahead of the descriptor they are
     // needed for.  Tickets only grow, so a wave stops at its first unit past the end.
-    const uint32_t nunits = (uint32_t)p.unit_end;
+    uint32_t ubegin = (uint32_t)p.unit_begin, nunits = (uint32_t)p.unit_end;
+    if (p.totals) {                                       // the slice comes from the device-side unit count
+        if (*p.abort) return;
+        const int64_t all = p.totals[1], first = all * p.first_permille / 1000;
+        ubegin = p.pass ? (uint32_t)first : 0u;
+        nunits = p.pass ? (uint32_t)all : (uint32_t)first;
+    }
     const uint32_t nc = (uint32_t)p.num_counters, cidx = blockIdx.x % nc;
     const uint32_t place = (blockIdx.x / nc) * 4u + (uint32_t)wave;
     const uint32_t places = ((gridDim.x - cidx + nc - 1u) / nc) * 4u;          // waves served by this counter
     unsigned int *ctr = p.tickets + cidx * 32u;
     auto unit_of = [&](uint32_t t) {
-        const unsigned long long uu = (unsigned long long)p.unit_begin + (unsigned long long)t * nc + cidx;
+        const unsigned long long uu = (unsigned long long)ubegin + (unsigned long long)t * nc + cidx;
         return uu < (unsigned long long)nunits ? (uint32_t)uu : nunits;
     };
     uint32_t u = unit_of(place), u_next = unit_of(place + places), u_after = unit_of(place + 2u * places);
@@ -1539,9 +1557,9 @@ __global__ __launch_bounds__(256, ls16_waves(KS, RB)) void k_leafscan_f16(LeafSc
 template <int METRIC, int RB>
 static void launch_leafscan_f16_m(const LeafScanParams &p, hipStream_t stream)
 {
-    const int64_t n = p.unit_end - p.unit_begin;
-    if (n <= 0) return;
     const int64_t resident = (int64_t)p.num_cus * ls16_waves(p.ks, RB);   // workgroups the chip holds at once
+    const int64_t n = p.totals ? resident * 4 : p.unit_end - p.unit_begin;
+    if (n <= 0) return;
     dim3 grid((unsigned)std::min<int64_t>((n + 3) / 4, resident)), block(256);
     LeafScanParams q = p;
     q.num_counters = (int32_t)std::min<int64_t>(p.num_counters, grid.x);     // every counter needs a workgroup

@@ -408,6 +408,59 @@ def test_bucket_major_many_queries_per_bucket_and_repeated_batches():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("metric", ["l2", "dot"])
+def test_list_sizes_carried_from_batch_to_batch(metric):
+    # After a handle's first bucket-major batch the host no longer waits for the batch's list sizes: the
+    # buffers keep the room earlier batches left, and a batch that outgrows them is abandoned on the
+    # device and run again.  Same answers in all three modes, through growing and shrinking batches,
+    # a change of search steps and a refit.
+    params, X, Q, pick = make_problem(n=6000, nq=2000, dim=64, bucket_overflow=80, table_num=3, permutation_num=1,
+                                      n_clusters=5)
+    fast = DpfIndex(params, metric=metric)
+    slow = DpfIndex(dict(params, flags=2), metric=metric)
+    fast.fit(X[:4000])
+    slow.fit(X[:4000])
+    seen = []
+    for nq, steps in ((5, 0), (5, 0), (2000, 1), (2000, 1), (300, 2), (40, 0), (2000, 3)):
+        fi, fs = fast.query_topk(pick[:nq], Q[:nq], steps=steps, k=10)
+        st = fast.stats()
+        assert st["last_path"] == 1
+        seen.append(st["last_sizes_carried"])
+        si, ss = slow.query_topk(pick[:nq], Q[:nq], steps=steps, k=10)
+        assert np.array_equal(fi, si) and np.array_equal(fs, ss, equal_nan=True), (nq, steps, seen)
+    assert seen[0] == 0 and seen[1] == 1 and seen[2] == 2 and seen[3] == 1 and seen[4] == 1 and seen[5] == 1, seen
+    fast.fit(X[4000:])
+    slow.fit(X[4000:])
+    for nq, steps in ((2000, 1), (100, 1)):
+        fi, fs = fast.query_topk(pick[:nq], Q[:nq], steps=steps, k=10)
+        assert fast.stats()["last_path"] == 1
+        si, ss = slow.query_topk(pick[:nq], Q[:nq], steps=steps, k=10)
+        assert np.array_equal(fi, si) and np.array_equal(fs, ss, equal_nan=True)
+
+
+@pytest.mark.gpu
+def test_carried_sizes_with_a_truncated_bucket_list(monkeypatch):
+    # a batch that did not wait for its sizes and then truncates a query's bucket list is run again
+    # with the second walk
+    params, X, Q, pick = make_problem(n=8000, nq=60, bucket_overflow=60, n_clusters=6, table_num=2, permutation_num=1)
+    slow = DpfIndex(dict(params, flags=2), metric="l2")
+    slow.fit(X)
+    fast = DpfIndex(params, metric="l2")
+    fast.fit(X)
+    seen = []
+    for i, steps in enumerate((1, 1, 1, 1, 0)):
+        if i == 2:
+            monkeypatch.setenv("DPF_Q_LEAF_CAP", "3")     # read at every batch
+        got = fast.query_topk(pick, Q, steps=steps, k=10)
+        st = fast.stats()
+        assert st["last_path"] == 1
+        seen.append(st["last_sizes_carried"])
+        want = slow.query_topk(pick, Q, steps=steps, k=10)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1], equal_nan=True), (steps, seen)
+    assert seen[:4] == [0, 1, 2, 0], seen
+
+
+@pytest.mark.gpu
 def test_bucket_major_truncated_bucket_lists_walk_again(monkeypatch):
     # the first probe pass remembers each query's buckets up to a cap; past it the lists are
     # filled by a second walk.  Same answer either way.
