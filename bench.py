@@ -180,8 +180,8 @@ def main():
 
     def step():
         # hash -> probe -> scan -> rerank on this rank's shard (of the tables, or of the rows for a
-        # single-table forest); with N > 1 one all-gather per
-        # array of the partial top-k lists and the merge kernel
+        # single-table forest); with N > 1 one all-gather of the packed
+        # partial top-k lists and the merge kernel
         sharded.query_topk(dqid, dQ, steps, k, d_ids, d_sc, torch.cuda.current_stream().cuda_stream)
 
     def fence():

@@ -176,6 +176,13 @@ int dpf_rerank(dpf_index *ix, const void *Q, int64_t nq, const int64_t *cand_off
 int dpf_merge_topk_device(dpf_index *ix, const int32_t *in_ids, const double *in_scores,
                           int32_t parts, int64_t nq, int32_t k, int32_t *d_ids, double *d_scores,
                           void *stream);
+/* The same merge over `parts` packed blocks of part_bytes each, as ONE all-gather
+ * of the handles' results delivers them: block s = scores [nq][k] (doubles) at its
+ * start, ids [nq][k] (int32) right behind them, padding up to part_bytes (a
+ * multiple of 8, at least nq*k*12; `in` 8-byte aligned).  No counterpart in the
+ * reference, which is a single process. */
+int dpf_merge_topk_packed_device(dpf_index *ix, const void *in, int64_t part_bytes, int32_t parts,
+                                 int64_t nq, int32_t k, int32_t *d_ids, double *d_scores, void *stream);
 
 /* A fitted handle to one file and back: configuration, hash family and
  * partitioner, the hashes of every id and the resident rows (the forest is

@@ -42,7 +42,7 @@ class DpfStats(C.Structure):
 EXPORTS = (
     "dpf_create", "dpf_destroy", "dpf_last_error", "dpf_set_hash_family", "dpf_set_partitioner",
     "dpf_set_sampling_index", "dpf_fit", "dpf_hash_batch", "dpf_query_batch", "dpf_free",
-    "dpf_query_topk", "dpf_query_topk_device", "dpf_rerank", "dpf_merge_topk_device",
+    "dpf_query_topk", "dpf_query_topk_device", "dpf_rerank", "dpf_merge_topk_device", "dpf_merge_topk_packed_device",
     "dpf_subindex_distribution", "dpf_get_stats", "dpf_last_rerank_profile", "dpf_set_profiling",
     "dpf_save", "dpf_load", "dpf_get_config", "dpf_snapshot_sizes", "dpf_snapshot_copy",
 )
@@ -94,6 +94,8 @@ def lib():
     L.dpf_rerank.argtypes = [vp, vp, C.c_int64, i64p, ip, C.c_int32, ip, dp]
     L.dpf_merge_topk_device.restype = C.c_int
     L.dpf_merge_topk_device.argtypes = [vp, vp, vp, C.c_int32, C.c_int64, C.c_int32, vp, vp, vp]
+    L.dpf_merge_topk_packed_device.restype = C.c_int
+    L.dpf_merge_topk_packed_device.argtypes = [vp, vp, C.c_int64, C.c_int32, C.c_int64, C.c_int32, vp, vp, vp]
     L.dpf_subindex_distribution.restype = C.c_int
     L.dpf_subindex_distribution.argtypes = [vp, dp]
     L.dpf_get_stats.restype = C.c_int
@@ -256,6 +258,9 @@ class DpfIndex:
 
     def merge_topk_device(self, in_ids, in_scores, parts, nq, k, d_ids, d_scores, stream=None):
         self._check(self.L_.dpf_merge_topk_device(self.h, in_ids, in_scores, parts, nq, k, d_ids, d_scores, stream))
+
+    def merge_topk_packed_device(self, blocks, part_bytes, parts, nq, k, d_ids, d_scores, stream=None):
+        self._check(self.L_.dpf_merge_topk_packed_device(self.h, blocks, part_bytes, parts, nq, k, d_ids, d_scores, stream))
 
     def rerank(self, Q, offsets, cand, k=None):
         Q = self._rows(Q)

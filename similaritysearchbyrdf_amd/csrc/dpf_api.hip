@@ -1288,7 +1288,22 @@ extern "C" int dpf_merge_topk_device(dpf_index *ix, const int32_t *in_ids, const
     if (parts < 1 || parts > 64 || k < 1 || nq < 0 || !in_ids || !in_scores || !d_ids || !d_scores)
         return fail(ix, DPF_EINVAL, "dpf_merge_topk_device: bad arguments");
     HIPCHECK(ix, hipSetDevice(ix->cfg.device));
-    launch_merge_topk(ix->cfg.metric, in_ids, in_scores, parts, nq, k, d_ids, d_scores, (hipStream_t)stream);
+    launch_merge_topk(ix->cfg.metric, in_ids, in_scores, parts, nq * k, nq * k, nq, k, d_ids, d_scores, (hipStream_t)stream);
+    HIPCHECK(ix, hipGetLastError());
+    return DPF_OK;
+}
+
+extern "C" int dpf_merge_topk_packed_device(dpf_index *ix, const void *in, int64_t part_bytes, int32_t parts, int64_t nq, int32_t k,
+                                            int32_t *d_ids, double *d_scores, void *stream)
+{
+    if (!ix) return DPF_EINVAL;
+    if (parts < 1 || parts > 64 || k < 1 || nq < 0 || !in || !d_ids || !d_scores || part_bytes % 8 != 0 ||
+        part_bytes < nq * k * 12 || ((uintptr_t)in & 7) != 0)
+        return fail(ix, DPF_EINVAL, "dpf_merge_topk_packed_device: bad arguments");
+    HIPCHECK(ix, hipSetDevice(ix->cfg.device));
+    const double *scores = (const double *)in;
+    const int32_t *ids = (const int32_t *)((const char *)in + (size_t)nq * k * 8);
+    launch_merge_topk(ix->cfg.metric, ids, scores, parts, part_bytes / 4, part_bytes / 8, nq, k, d_ids, d_scores, (hipStream_t)stream);
     HIPCHECK(ix, hipGetLastError());
     return DPF_OK;
 }

@@ -149,8 +149,8 @@ void launch_rerank(int dtype, int metric, const RerankParams &p, int64_t nq, hip
 int rerank_max_chunks16();
 bool rerank_short_applies(const RerankParams &p);
 void launch_rerank_short(int dtype, int metric, const RerankParams &p, int64_t nq, hipStream_t stream);
-void launch_merge_topk(int metric, const int32_t *in_ids, const double *in_scores, int parts,
-                       int64_t nq, int k, int32_t *out_ids, double *out_scores, hipStream_t stream);
+void launch_merge_topk(int metric, const int32_t *in_ids, const double *in_scores, int parts, int64_t ids_stride,
+                       int64_t scores_stride, int64_t nq, int k, int32_t *out_ids, double *out_scores, hipStream_t stream);
 void launch_copy_rows(int dtype, const void *src, int64_t n, int dim, void *dst, int64_t dst_stride,
                       hipStream_t stream);
 int configure_kernels();

@@ -1852,8 +1852,8 @@ void launch_unique_lists(int32_t *emit, const int32_t *emit_cnt, int32_t cap, in
 // ---------------------------------------------------------------------------
 template <int METRIC>
 __global__ void k_merge_topk(const int32_t *__restrict__ in_ids, const double *__restrict__ in_scores,
-                             int parts, int64_t nq, int k, int32_t *__restrict__ out_ids,
-                             double *__restrict__ out_scores)
+                             int parts, int64_t ids_stride, int64_t scores_stride, int64_t nq, int k,
+                             int32_t *__restrict__ out_ids, double *__restrict__ out_scores)
 {
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nq) return;
@@ -1864,10 +1864,10 @@ __global__ void k_merge_topk(const int32_t *__restrict__ in_ids, const double *_
         double bs = 0; int32_t bi = 0;
         for (int s = 0; s < parts; s++) {
             if (head[s] >= k) continue;
-            const int64_t at = ((int64_t)s * nq + q) * k + head[s];
-            const int32_t id = in_ids[at];
+            const int64_t at = q * k + head[s];
+            const int32_t id = in_ids[s * ids_stride + at];
             if (id < 0) { head[s] = k; continue; }
-            const double sc = in_scores[at];
+            const double sc = in_scores[s * scores_stride + at];
             if (best < 0 || better<METRIC>(sc, id, bs, bi)) { best = s; bs = sc; bi = id; }
         }
         if (best < 0) { out_ids[q * k + e] = -1; out_scores[q * k + e] = nan(""); continue; }
@@ -1876,19 +1876,20 @@ __global__ void k_merge_topk(const int32_t *__restrict__ in_ids, const double *_
         // lists of table shards can hold the same row (same exact score): it sits at the head of
         // every list that has it, and is taken once
         for (int s = 0; s < parts; s++)
-            if (head[s] < k && in_ids[((int64_t)s * nq + q) * k + head[s]] == bi) head[s]++;
+            if (head[s] < k && in_ids[s * ids_stride + q * k + head[s]] == bi) head[s]++;
     }
 }
 
-void launch_merge_topk(int metric, const int32_t *in_ids, const double *in_scores, int parts,
-                       int64_t nq, int k, int32_t *out_ids, double *out_scores, hipStream_t stream)
+// list s of the ids starts ids_stride elements behind list s-1, of the scores scores_stride elements
+void launch_merge_topk(int metric, const int32_t *in_ids, const double *in_scores, int parts, int64_t ids_stride,
+                       int64_t scores_stride, int64_t nq, int k, int32_t *out_ids, double *out_scores, hipStream_t stream)
 {
     if (nq <= 0) return;
     unsigned grid = (unsigned)((nq + 127) / 128);
     if (metric == 0)
-        hipLaunchKernelGGL((k_merge_topk<0>), dim3(grid), dim3(128), 0, stream, in_ids, in_scores, parts, nq, k, out_ids, out_scores);
+        hipLaunchKernelGGL((k_merge_topk<0>), dim3(grid), dim3(128), 0, stream, in_ids, in_scores, parts, ids_stride, scores_stride, nq, k, out_ids, out_scores);
     else
-        hipLaunchKernelGGL((k_merge_topk<1>), dim3(grid), dim3(128), 0, stream, in_ids, in_scores, parts, nq, k, out_ids, out_scores);
+        hipLaunchKernelGGL((k_merge_topk<1>), dim3(grid), dim3(128), 0, stream, in_ids, in_scores, parts, ids_stride, scores_stride, nq, k, out_ids, out_scores);
 }
 
 // Dynamic LDS above 64 KiB has to be opted into per kernel.

@@ -1,9 +1,9 @@
 """Sharded multi-GPU batch query: one process per GPU, torch.distributed
 (backend "nccl" = RCCL over xGMI; "gloo" for CPU rehearsal).
 
-Two ways to split one batch, both ending in the same exchange (one all-gather
-per array of the per-rank top-k lists, then a merge by score, then id, with
-repeated ids taken once):
+Two ways to split one batch, both ending in the same exchange (ONE all-gather
+of the per-rank top-k lists, ids and scores packed into one block per rank,
+then a merge by score, then id, with repeated ids taken once):
 
 * "tables" (used when the forest has at least as many tables as there are
   ranks): everything is replicated; the G ranks form a grid of QG query groups
@@ -80,20 +80,46 @@ def merge_topk_host(ids, scores, metric):
     return out_ids, out_sc
 
 
-def exchange(local_ids, local_scores, group=None):
-    """all-gather the [nq, k] partial lists of every rank -> ([G, nq, k], [G, nq, k])."""
+def packed_bytes(m, k):
+    """Bytes of one rank's packed block: scores [m, k] float64, ids [m, k] int32, padded to 8."""
+    return (m * k * 12 + 7) // 8 * 8
+
+
+def packed_views(block, m, k):
+    """(scores [.., m, k] float64, ids [.., m, k] int32) views into packed blocks [.., packed_bytes(m, k)] (uint8)."""
+    import torch
+    n = m * k
+    lead = tuple(block.shape[:-1])
+    return (block[..., :n * 8].view(torch.float64).view(lead + (m, k)),
+            block[..., n * 8:n * 12].view(torch.int32).view(lead + (m, k)))
+
+
+def exchange_packed(block, out=None, group=None):
+    """ONE all-gather of every rank's packed block [B] (uint8) -> [G, B]."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
-    if dist.get_backend(group) == "gloo" and local_ids.is_cuda:
+    if dist.get_backend(group) == "gloo" and block.is_cuda:
         # CPU rehearsal of the exchange with device-resident lists (several ranks sharing one GPU)
-        c_ids, c_sc = exchange(local_ids.cpu(), local_scores.cpu(), group)
-        return c_ids.to(local_ids.device), c_sc.to(local_scores.device)
-    g_ids = torch.empty((world,) + tuple(local_ids.shape), dtype=local_ids.dtype, device=local_ids.device)
-    g_sc = torch.empty((world,) + tuple(local_scores.shape), dtype=local_scores.dtype, device=local_scores.device)
-    # concatenated-along-dim-0 output form: accepted by both RCCL and gloo
-    dist.all_gather_into_tensor(g_ids.view((-1,) + tuple(local_ids.shape[1:])), local_ids.contiguous(), group=group)
-    dist.all_gather_into_tensor(g_sc.view((-1,) + tuple(local_scores.shape[1:])), local_scores.contiguous(), group=group)
+        g = exchange_packed(block.cpu(), None, group).to(block.device)
+        if out is not None:
+            out.copy_(g)
+            return out
+        return g
+    g = out if out is not None else torch.empty((world, block.numel()), dtype=torch.uint8, device=block.device)
+    dist.all_gather_into_tensor(g.view(-1), block, group=group)
+    return g
+
+
+def exchange(local_ids, local_scores, group=None):
+    """all-gather the [nq, k] partial lists of every rank -> ([G, nq, k], [G, nq, k]), packed into one collective."""
+    import torch
+    m, k = local_ids.shape
+    block = torch.zeros(packed_bytes(m, k), dtype=torch.uint8, device=local_ids.device)
+    sc, ids = packed_views(block, m, k)
+    sc.copy_(local_scores)
+    ids.copy_(local_ids)
+    g_sc, g_ids = packed_views(exchange_packed(block, None, group), m, k)
     return g_ids, g_sc
 
 
@@ -143,28 +169,30 @@ class ShardedDpf:
         qg, tg = self.qg, self.tg
         q_lo, q_hi = shard_bounds(nq, qg, self.rank // tg)        # this rank's query group
         m = -(-nq // qg)                                           # rows every rank contributes to the exchange
-        if self._bufs is None or self._bufs[0].shape != (m, k):
+        if self._bufs is None or self._bufs[0] != (m, k):
             dev = d_Q.device
-            self._bufs = (torch.full((m, k), -1, dtype=torch.int32, device=dev),
-                          torch.zeros((m, k), dtype=torch.float64, device=dev),
+            block = torch.zeros(packed_bytes(m, k), dtype=torch.uint8, device=dev)
+            l_sc, l_ids = packed_views(block, m, k)
+            l_ids.fill_(-1)                                        # rows past this rank's query group stay empty lists
+            self._bufs = ((m, k), block, l_ids, l_sc,
+                          torch.empty((self.world, block.numel()), dtype=torch.uint8, device=dev),
                           torch.empty((m, k), dtype=torch.int32, device=dev),
                           torch.empty((m, k), dtype=torch.float64, device=dev))
-        l_ids, l_sc, t_ids, t_sc = self._bufs
+        _, block, l_ids, l_sc, gathered, t_ids, t_sc = self._bufs
         if q_hi > q_lo:
             qid_ptr = d_qids[q_lo:q_hi].data_ptr() if d_qids is not None else None
             self.index.query_topk_device(qid_ptr, d_Q[q_lo:q_hi].data_ptr(), q_hi - q_lo, steps, k, l_ids.data_ptr(),
                                          l_sc.data_ptr(), stream)
-        g_ids, g_sc = exchange(l_ids, l_sc, self.group)            # [G, m, k]
+        exchange_packed(block, gathered, self.group)               # [G, packed block]: one collective per batch
         for j in range(qg):
             lo, hi = shard_bounds(nq, qg, j)
             if hi == lo:
                 continue
-            src_i, src_s = g_ids[j * tg:(j + 1) * tg], g_sc[j * tg:(j + 1) * tg]
+            src = gathered[j * tg].data_ptr()                      # the tg blocks of query group j sit back to back
             if hi - lo == m:
-                self.index.merge_topk_device(src_i.data_ptr(), src_s.data_ptr(), tg, m, k, out_ids[lo:hi].data_ptr(),
-                                             out_scores[lo:hi].data_ptr(), stream)
+                self.index.merge_topk_packed_device(src, block.numel(), tg, m, k, out_ids[lo:hi].data_ptr(),
+                                                    out_scores[lo:hi].data_ptr(), stream)
             else:                                                  # a short last group: merge all m rows aside
-                self.index.merge_topk_device(src_i.data_ptr(), src_s.data_ptr(), tg, m, k, t_ids.data_ptr(),
-                                             t_sc.data_ptr(), stream)
+                self.index.merge_topk_packed_device(src, block.numel(), tg, m, k, t_ids.data_ptr(), t_sc.data_ptr(), stream)
                 out_ids[lo:hi].copy_(t_ids[:hi - lo])
                 out_scores[lo:hi].copy_(t_sc[:hi - lo])

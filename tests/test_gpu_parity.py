@@ -186,6 +186,24 @@ def test_row_shards_and_merge():
     g.merge_topk_device(t_ids.data_ptr(), t_sc.data_ptr(), 4, 24, 10, o_ids.data_ptr(), o_sc.data_ptr())
     torch.cuda.synchronize()
     assert_topk_equal(o_ids.cpu().numpy(), o_sc.cpu().numpy(), want[0], want[1])
+    # the same lists as packed blocks (scores, then ids, per part), the form one all-gather delivers;
+    # k = 7 leaves a block that needs padding to 8 bytes (24 * 7 * 12 = 2016 + 0; 23 queries: 1932 -> 1936)
+    from similaritysearchbyrdf_amd.dist import packed_bytes, packed_views
+    for nq, k in ((24, 10), (23, 7)):
+        pb = packed_bytes(nq, k)
+        blocks = torch.zeros((4, pb), dtype=torch.uint8, device=dev)
+        b_sc, b_ids = packed_views(blocks, nq, k)
+        b_sc.copy_(t_sc[:, :nq, :k])
+        b_ids.copy_(t_ids[:, :nq, :k])
+        p_ids = torch.empty((nq, k), dtype=torch.int32, device=dev)
+        p_sc = torch.empty((nq, k), dtype=torch.float64, device=dev)
+        g.merge_topk_packed_device(blocks.data_ptr(), pb, 4, nq, k, p_ids.data_ptr(), p_sc.data_ptr())
+        c_ids = torch.empty((nq, k), dtype=torch.int32, device=dev)
+        c_sc = torch.empty((nq, k), dtype=torch.float64, device=dev)
+        s_ids, s_sc = t_ids[:, :nq, :k].contiguous(), t_sc[:, :nq, :k].contiguous()
+        g.merge_topk_device(s_ids.data_ptr(), s_sc.data_ptr(), 4, nq, k, c_ids.data_ptr(), c_sc.data_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(p_ids, c_ids) and np.array_equal(p_sc.cpu().numpy(), c_sc.cpu().numpy(), equal_nan=True)
 
 
 def test_incremental_fit_equals_one_fit():
