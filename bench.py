@@ -16,10 +16,13 @@ Workloads (BASELINE.json `configs`):
       GloVe itself is not available offline: clustered synthetic vectors of the same shape.
   c2  same data, a single tree, 0-step search (configs[1]).
   c4  128-d SIFT-shaped integer-valued vectors, 1M / 10k, forest as c3.
+  c5  768-d unit-normalised Gaussian vectors, forest as c3 over a family of 768 functions
+      (configs[4] is 10M / 100k on 8 GPUs: pass --base-rows / --queries for the share to run).
 
-With N > 1 the forest is replicated, base rows are sharded N ways, every rank
-reranks the candidates that fall in its shard, and the per-shard top-k lists are
-all-gathered (RCCL) and merged: total work is fixed, so scaling is "strong".
+With N > 1 everything is replicated and the ranks form a grid of query groups x table
+groups: a rank answers its query group from its range of the trees, the per-rank top-k
+lists are all-gathered (RCCL, one collective) and merged: total work is fixed, so
+scaling is "strong".  Single-tree forests shard the base rows instead.
 """
 import argparse
 import json
@@ -51,6 +54,11 @@ def workload(name, n, nq):
         params = synthetic.make_family(128, table_num=10, permutation_num=3, chain_length=32, family="angle",
                                        family_size=128, partition_bits=3, orthogonal=True)
         X, Q, pick = synthetic.make_sift_like(n, 128, nq)
+        steps = 1
+    elif name == "c5":
+        params = synthetic.make_family(768, table_num=10, permutation_num=3, chain_length=32, family="angle",
+                                       family_size=768, partition_bits=3, orthogonal=True)
+        X, Q, pick = synthetic.make_unit_gaussian(n, 768, nq)
         steps = 1
     else:
         raise SystemExit("unknown workload " + name)

@@ -363,7 +363,7 @@ static int upload_snapshot(dpf_index *ix, ForestSnapshot &s)
         s.leaf_off.swap(off);
     }
     std::vector<uint32_t> tiles, leaf_tile0(s.leaf_off.size(), 0u);
-    const uint32_t TR = 64;                               // rows per work-unit tile of the scan
+    const uint32_t TR = (uint32_t)leafscan_tile_rows(ix->ks16);   // rows per work-unit tile of the scan
     for (size_t l = 0; l + 1 < s.leaf_off.size(); l++) {
         const uint32_t len = s.leaf_off[l + 1] - s.leaf_off[l];
         leaf_tile0[l] = (uint32_t)(tiles.size() / 4);
@@ -426,7 +426,7 @@ static int device_snapshot(dpf_index *ix, int64_t total)
     uint32_t *lt0 = nullptr;
     uint4 *tiles = nullptr;
     int64_t ntiles = 0;
-    if (make_forest_tiles(f, 64, &lt0, &tiles, &ntiles, err) != 0) {
+    if (make_forest_tiles(f, leafscan_tile_rows(ix->ks16), &lt0, &tiles, &ntiles, err) != 0) {
         if (lt0) (void)hipFree(lt0);
         if (tiles) (void)hipFree(tiles);
         f.release();

@@ -127,6 +127,7 @@ void launch_units(const uint32_t *lq_cnt, const int64_t *lq_off, const uint32_t 
 void launch_tile_maxnorm(uint4 *tiles, int64_t ntiles, const int32_t *ids, const float *norms, const float *errs, int64_t row_begin,
                          int64_t row_end, float *slot_norms, hipStream_t stream);
 int leafscan_f16_steps(int dim);
+int leafscan_tile_rows(int ks);
 void launch_refine(int metric, const int32_t *emit, const float *emit_v, const int32_t *emit_cnt, int32_t cap, int k, int64_t nq,
                    const float *q16_err, int32_t *tau, hipStream_t stream);
 void launch_rows_to_f16(const float *src, int64_t src_stride, int dim, int64_t n, uint16_t *dst, int dst_stride,

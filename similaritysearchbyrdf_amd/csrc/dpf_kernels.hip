@@ -1245,6 +1245,17 @@ void launch_tile_maxnorm(uint4 *tiles, int64_t ntiles, const int32_t *ids, const
 // two norms, and the roundings of the threshold arithmetic.
 __device__ __forceinline__ float leafscan_c32(int stride) { return (5.0f * (float)(stride + 8) + 24.0f) * 5.9604645e-8f; }
 
+// the largest of a lane's scores for accumulator register r over the tile's 16-row blocks
+template <int RB>
+__device__ __forceinline__ float best_of(const f32x4 (&acc)[RB], int r)
+{
+    if constexpr (RB == 4) return fmaxf(fmaxf(acc[0][r], acc[1][r]), fmaxf(acc[2][r], acc[3][r]));
+    float m = acc[0][r];
+#pragma unroll
+    for (int rb = 1; rb < RB; rb++) m = fmaxf(m, acc[rb][r]);
+    return m;
+}
+
 // The queries of one unit against the tile a wave holds in registers, 16 at a time: thresholds,
 // products on the matrix cores, tests, forwarding.  s_* are this wave's LDS areas: forwarded (query,
 // id, bound) triples parked until 64 are there; per query slot the threshold G, and for the rare
@@ -1267,7 +1278,11 @@ __device__ __forceinline__ void leafscan_chunks(const LeafScanParams &p, const u
                                                 uint32_t lq0, float xrm, float cxm, int32_t qsc, int32_t qsn, int32_t *s_fq,
                                                 int32_t *s_fid, float *s_fv, float4 *s_slot, float *s_G, int32_t *s_qid, int &nbuf)
 {
-    static_assert(RB == 4, "the tests below are written for 64-row tiles");
+    static_assert(RB == 4 || RB == 1, "64-row tiles, or 16-row tiles for rows of more than 256 dimensions");
+    // rows longer than 8 steps are scanned 16 at a time (RB == 1): a 64-row tile of them does not fit the
+    // register file; their query rows come in slices of QS steps
+    constexpr int QS = KS > 8 ? 8 : KS;
+    static_assert(KS % QS == 0, "whole slices");
     const int lane = threadIdx.x & 63;
     const int i16 = lane & 15, g = lane >> 4;
     const uint32_t jq = 4u * (uint32_t)(i16 & 3) + (uint32_t)(i16 >> 2);   // chunk position of this lane's MFMA row
@@ -1285,13 +1300,11 @@ __device__ __forceinline__ void leafscan_chunks(const LeafScanParams &p, const u
     };
 
     for (uint32_t c = 0; c < nq; c += 16u) {
-        f16x8 qa[KS];
+        f16x8 qa[QS];
         const size_t qat = (size_t)(qsc >= 0 ? qsc : 0);
-        {
-            const uint16_t *qrow = Q16 + ((p.debug & 2) ? (qat & 15) : qat) * STRIDE + 8 * g;   // debug 2: all query rows from one hot spot (timing only)
+        const uint16_t *qrow = Q16 + ((p.debug & 2) ? (qat & 15) : qat) * STRIDE + 8 * g;   // debug 2: all query rows from one hot spot (timing only)
 #pragma unroll
-            for (int t = 0; t < KS; t++) qa[t] = *(const f16x8 *)(qrow + 32 * t);
-        }
+        for (int t = 0; t < QS; t++) qa[t] = *(const f16x8 *)(qrow + 32 * t);
         const float m_tau = dec_f32(__hip_atomic_load(&p.tau[qat], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         const float4 qc = p.qc[qat];
         const int32_t qcur = qsc;
@@ -1320,12 +1333,30 @@ __device__ __forceinline__ void leafscan_chunks(const LeafScanParams &p, const u
             }
         }
         f32x4 acc[RB];
+        if constexpr (KS == QS) {
 #pragma unroll
-        for (int rb = 0; rb < RB; rb++) {
-            acc[rb] = (f32x4){nJ[rb], nJ[rb], nJ[rb], nJ[rb]};
-            if (rb * 16u >= rows && rb > 0) continue;
+            for (int rb = 0; rb < RB; rb++) {
+                acc[rb] = (f32x4){nJ[rb], nJ[rb], nJ[rb], nJ[rb]};
+                if (rb * 16u >= rows && rb > 0) continue;
 #pragma unroll
-            for (int t = 0; t < KS; t++) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qa[t], xb[rb][t], acc[rb], 0, 0, 0);
+                for (int t = 0; t < KS; t++) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qa[t], xb[rb][t], acc[rb], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int rb = 0; rb < RB; rb++) acc[rb] = (f32x4){nJ[rb], nJ[rb], nJ[rb], nJ[rb]};
+#pragma unroll
+            for (int s0 = 0; s0 < KS; s0 += QS) {
+                if (s0 > 0) {
+#pragma unroll
+                    for (int t = 0; t < QS; t++) qa[t] = *(const f16x8 *)(qrow + 32 * (s0 + t));
+                }
+#pragma unroll
+                for (int rb = 0; rb < RB; rb++) {
+                    if (rb * 16u >= rows && rb > 0) continue;
+#pragma unroll
+                    for (int t = 0; t < QS; t++) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qa[t], xb[rb][s0 + t], acc[rb], 0, 0, 0);
+                }
+            }
         }
         // lane l holds d = q~(MFMA row 4g + r) . x~(rb*16 + i16) - J in acc[rb][r]
         if (p.debug & 1) {                            // ablation runs: loads and products only
@@ -1338,17 +1369,17 @@ __device__ __forceinline__ void leafscan_chunks(const LeafScanParams &p, const u
         // the common case first: nothing of this lane's 16 scores reaches its query's threshold
         {
             const float4 Gs = *(const float4 *)(s_G + 4 * g);
-            const float e0 = fmaxf(fmaxf(acc[0][0], acc[1][0]), fmaxf(acc[2][0], acc[3][0])) - Gs.x;
-            const float e1 = fmaxf(fmaxf(acc[0][1], acc[1][1]), fmaxf(acc[2][1], acc[3][1])) - Gs.y;
-            const float e2 = fmaxf(fmaxf(acc[0][2], acc[1][2]), fmaxf(acc[2][2], acc[3][2])) - Gs.z;
-            const float e3 = fmaxf(fmaxf(acc[0][3], acc[1][3]), fmaxf(acc[2][3], acc[3][3])) - Gs.w;
+            const float e0 = best_of<RB>(acc, 0) - Gs.x;
+            const float e1 = best_of<RB>(acc, 1) - Gs.y;
+            const float e2 = best_of<RB>(acc, 2) - Gs.z;
+            const float e3 = best_of<RB>(acc, 3) - Gs.w;
             if (__ballot(fmaxf(fmaxf(e0, e1), fmaxf(e2, e3)) >= 0.f) == 0) continue;
         }
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int slot = 4 * g + r;
             const float Gr = s_G[slot];
-            if (__ballot(fmaxf(fmaxf(acc[0][r], acc[1][r]), fmaxf(acc[2][r], acc[3][r])) >= Gr) == 0) continue;
+            if (__ballot(best_of<RB>(acc, r) >= Gr) == 0) continue;
             const float4 sc = s_slot[slot];           // {G2, query index, |q - q~| or slack, |q~|^2}
             const int32_t qq = __float_as_int(sc.y), qidq = s_qid[slot];
             int tight = 0;                            // this lane's rows inside the trigger level
@@ -1409,7 +1440,7 @@ __device__ __forceinline__ void leafscan_chunks(const LeafScanParams &p, const u
                 // is rare, and keeping four ranks at once costs registers the whole kernel would pay for
 #pragma nounroll
                 for (int mb = 0; mb < RB; mb++) {
-                    const float mine = mb == 0 ? v[0] : mb == 1 ? v[1] : mb == 2 ? v[2] : v[3];
+                    const float mine = mb == 0 ? v[0] : mb == 1 ? v[1 % RB] : mb == 2 ? v[2 % RB] : v[3 % RB];
                     int rank = 0;
 #pragma nounroll
                     for (int j = 0; j < 16; j++) {
@@ -1449,7 +1480,7 @@ __device__ __forceinline__ void leafscan_flush_rest(const LeafScanParams &p, con
 // first queries) and once per further chunk; the other waves of the SIMD fill those waits.
 // RB*16 rows per tile: 64 measured best on gfx950 (32-row tiles double the per-unit work and
 // were 1.9x slower in spite of the higher occupancy).
-constexpr int ls16_waves(int ks, int rb) { return rb == 2 ? (ks >= 8 ? 2 : 4) : (ks >= 8 ? 2 : LS16_WAVES4); }
+constexpr int ls16_waves(int ks, int rb) { return ks >= 8 ? 2 : LS16_WAVES4; }
 
 template <int KS, int METRIC, int RB>
 __global__ __launch_bounds__(256, ls16_waves(KS, RB)) void k_leafscan_f16(LeafScanParams p, const uint16_t *__restrict__ Q16,
@@ -1564,11 +1595,19 @@ static void launch_leafscan_f16_m(const LeafScanParams &p, hipStream_t stream)
     LeafScanParams q = p;
     q.num_counters = (int32_t)std::min<int64_t>(p.num_counters, grid.x);     // every counter needs a workgroup
 #define DPF_LB(KS) hipLaunchKernelGGL((k_leafscan_f16<KS, METRIC, RB>), grid, block, 0, stream, q, q.Q16, q.base16)
-    switch (p.ks) {
-    case 1: DPF_LB(1); break;
-    case 2: DPF_LB(2); break;
-    case 4: DPF_LB(4); break;
-    default: DPF_LB(8); break;
+    if constexpr (RB == 4) {
+        switch (p.ks) {
+        case 1: DPF_LB(1); break;
+        case 2: DPF_LB(2); break;
+        case 4: DPF_LB(4); break;
+        default: DPF_LB(8); break;
+        }
+    } else {
+        switch (p.ks) {
+        case 16: DPF_LB(16); break;
+        case 24: DPF_LB(24); break;
+        default: DPF_LB(32); break;
+        }
     }
 #undef DPF_LB
 }
@@ -1631,14 +1670,18 @@ void launch_refine(int metric, const int32_t *emit, const float *emit_v, const i
     else hipLaunchKernelGGL((k_refine<1>), grid, block, 0, stream, emit, emit_v, emit_cnt, cap, k, nq, q16_err, tau);
 }
 
-// fp16 steps (of 32 dimensions) a padded row takes: 1, 2, 4 or 8; -1 when the row is too long
+// fp16 steps (of 32 dimensions) a padded row takes: 1, 2, 4, 8 (64-row tiles), 16, 24 or 32 (16-row tiles);
+// -1 when the row is too long
 int leafscan_f16_steps(int dim)
 {
     const int ks = (dim + 31) / 32;
     if (ks <= 1) return 1;
     if (ks <= 2) return 2;
     if (ks <= 4) return 4;
-    return ks <= 8 ? 8 : -1;
+    if (ks <= 8) return 8;
+    if (ks <= 16) return 16;
+    if (ks <= 24) return 24;
+    return ks <= 32 ? 32 : -1;
 }
 
 // fp32 rows (stride src_stride floats, `dim` meaningful) -> fp16 rows of dst_stride elements (a
@@ -1648,7 +1691,7 @@ int leafscan_f16_steps(int dim)
 __global__ void k_rows_to_f16(const float *__restrict__ src, int64_t src_stride, int dim, int64_t n,
                                uint16_t *__restrict__ dst, int dst_stride, float *__restrict__ norms, float *__restrict__ errs)
 {
-    const int per_row = dst_stride >> 3;                  // lanes per row: 4, 8, 16 or 32
+    const int per_row = dst_stride >> 3;                  // lanes per row: a power of two up to 64
     const int64_t total = n * per_row;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < total;
@@ -1681,10 +1724,50 @@ __global__ void k_rows_to_f16(const float *__restrict__ src, int64_t src_stride,
     for (int m = 1; m < per_row; m <<= 1) { ss += __shfl_xor(ss, m); ee += __shfl_xor(ee, m); }   // rows never straddle a wave
     if (live && c0 == 0) { norms[r] = ss; errs[r] = sqrtf(ee * 1.0001f) * 1.00001f; }
 }
+// The same for rows of more than 512 elements (or a stride that is no power of two): one wave per row,
+// a lane converts 8 consecutive elements of every 512.
+__global__ __launch_bounds__(256) void k_rows_to_f16_long(const float *__restrict__ src, int64_t src_stride, int dim, int64_t n,
+                                                          uint16_t *__restrict__ dst, int dst_stride, float *__restrict__ norms,
+                                                          float *__restrict__ errs)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;                                   // whole waves leave together
+    float ss = 0.f, ee = 0.f;
+    for (int c0 = lane * 8; c0 < dst_stride; c0 += 512) {
+        uint16_t o[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            o[e] = 0;
+            if (c0 + e < dim) {
+                const float x = src[r * src_stride + c0 + e];
+                _Float16 h = (_Float16)fminf(fmaxf(x, -65504.0f), 65504.0f);
+                if (fabsf((float)h) < 6.103515625e-5f) h = (_Float16)0.0f;
+                o[e] = __builtin_bit_cast(uint16_t, h);
+                const float f = (float)h;
+                ss = fmaf(f, f, ss);
+                const float df = x - f;
+                ee = fmaf(df, df, ee);
+            }
+        }
+        uint4 w;
+        w.x = o[0] | ((uint32_t)o[1] << 16); w.y = o[2] | ((uint32_t)o[3] << 16);
+        w.z = o[4] | ((uint32_t)o[5] << 16); w.w = o[6] | ((uint32_t)o[7] << 16);
+        *(uint4 *)(dst + r * dst_stride + c0) = w;
+    }
+    for (int m = 1; m < 64; m <<= 1) { ss += __shfl_xor(ss, m); ee += __shfl_xor(ee, m); }
+    if (lane == 0) { norms[r] = ss; errs[r] = sqrtf(ee * 1.0001f) * 1.00001f; }
+}
 void launch_rows_to_f16(const float *src, int64_t src_stride, int dim, int64_t n, uint16_t *dst, int dst_stride,
                          float *norms, float *errs, hipStream_t stream)
 {
     if (n <= 0) return;
+    const int per_row = dst_stride / 8;
+    if (per_row > 64 || (per_row & (per_row - 1)) != 0) {
+        hipLaunchKernelGGL(k_rows_to_f16_long, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, src, src_stride, dim, n, dst,
+                           dst_stride, norms, errs);
+        return;
+    }
     const int64_t total = n * (dst_stride / 8);
     hipLaunchKernelGGL(k_rows_to_f16, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, src, src_stride, dim, n,
                        dst, dst_stride, norms, errs);
@@ -1724,9 +1807,17 @@ void launch_tau(int metric, const double *seed_scores, const int32_t *seed_ids, 
 
 void launch_leafscan(int metric, const LeafScanParams &p, hipStream_t stream)
 {
+    if (p.ks > 8) {
+        if (metric == 0) launch_leafscan_f16_m<0, 1>(p, stream);
+        else launch_leafscan_f16_m<1, 1>(p, stream);
+        return;
+    }
     if (metric == 0) launch_leafscan_f16_m<0, 4>(p, stream);
     else launch_leafscan_f16_m<1, 4>(p, stream);
 }
+
+// rows per tile of the scan for rows of `ks` fp16 steps
+int leafscan_tile_rows(int ks) { return ks > 8 ? 16 : 64; }
 
 // flag[0] = number of queries whose forward list overflowed, their indices in list[];
 // flag[2] = the longest forward list of the batch

@@ -98,3 +98,18 @@ def make_sift_like(n, dim, nq, seed=99, dtype=np.float32):
     pick = rng.integers(0, n, size=nq)
     Q = np.clip(np.rint(X[pick] + 4.0 * rng.standard_normal((nq, dim), dtype=np.float32)), 0, 255).astype(dtype)
     return X, Q, pick
+
+
+def make_unit_gaussian(n, dim, nq, noise=0.05, seed=777, dtype=np.float32, chunk=100000):
+    """Unit-normalised N(0, I) vectors; queries are base rows plus N(0, noise^2 / dim) noise per
+    component, normalised again.  -> (X [n,dim], Q [nq,dim], picked rows)."""
+    rng = np.random.default_rng(seed)
+    X = np.empty((n, dim), dtype=dtype)
+    for s in range(0, n, chunk):
+        e = min(n, s + chunk)
+        v = rng.standard_normal((e - s, dim), dtype=np.float32)
+        X[s:e] = v / np.linalg.norm(v, axis=1, keepdims=True)
+    pick = rng.integers(0, n, size=nq)
+    q = X[pick] + (noise / np.sqrt(dim)) * rng.standard_normal((nq, dim), dtype=np.float32)
+    Q = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(dtype)
+    return X, Q, pick

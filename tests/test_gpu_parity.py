@@ -315,9 +315,9 @@ def test_full_size_properties():
 
 
 @pytest.mark.parametrize("metric", ["l2", "dot"])
-@pytest.mark.parametrize("dim", [100, 50, 128, 24, 200, 256])
+@pytest.mark.parametrize("dim", [100, 50, 128, 24, 200, 256, 300, 512, 768, 1000])
 def test_bucket_major_rerank_equals_gather_rerank(metric, dim):
-    # f32 handles of up to 256 dimensions rerank bucket-major (fp16 filter with measured rounding
+    # f32 handles of up to 1024 dimensions rerank bucket-major (fp16 filter with measured rounding
     # bounds + exact fp64 rerank of the survivors); the per-query gather kernel scores every
     # candidate in fp64.  Same ids, same scores, bit for bit.
     params, X, Q, pick = make_problem(n=20000, nq=300, dim=dim, bucket_overflow=80, table_num=3, permutation_num=2,
@@ -376,11 +376,13 @@ def test_bucket_major_with_row_shards():
 @pytest.mark.gpu
 @pytest.mark.parametrize("metric", ["l2", "dot"])
 @pytest.mark.parametrize("kind", ["huge", "tiny", "mixed", "near_duplicates", "zeros"])
-def test_fp16_filter_is_exact_on_hostile_values(metric, kind):
+@pytest.mark.parametrize("dim", [100, 700])
+def test_fp16_filter_is_exact_on_hostile_values(metric, kind, dim):
     # The bucket-major filter works on fp16 copies whose rounding distance is measured per row, so
     # values outside the fp16 range (clamped), below its normal range (flushed) or differing only
     # in bits fp16 drops must still give the gather path's answer bit for bit.
-    params, X, Q, pick = make_problem(n=6000, nq=120, dim=100, bucket_overflow=40, table_num=2, permutation_num=2,
+    # (700 dimensions: the 16-row-tile form of the scan)
+    params, X, Q, pick = make_problem(n=6000, nq=120, dim=dim, bucket_overflow=40, table_num=2, permutation_num=2,
                                       n_clusters=5)
     rng = np.random.default_rng(7)
     if kind == "huge":
