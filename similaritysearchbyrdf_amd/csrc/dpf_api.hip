@@ -183,7 +183,7 @@ extern "C" int dpf_create(const dpf_config *cfg, dpf_index **out)
     const int64_t per16 = 16 / (int64_t)ix->elem;
     ix->dpad = (cfg->dim + per16 - 1) / per16 * per16;
     if (cfg->dtype == DPF_F32 && !(cfg->flags & DPF_FLAG_GATHER_ONLY) && !getenv("DPF_GATHER_ONLY")) {
-        // the bucket-major scan works on fp16 copies of up to 256 dimensions
+        // the bucket-major scan works on fp16 copies of up to 1024 dimensions
         ix->ks16 = leafscan_f16_steps(cfg->dim);
         ix->bucket_major = ix->ks16 > 0;
     }

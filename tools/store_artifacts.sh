@@ -5,6 +5,7 @@ cp gpurun_out/final_c3.log profiles/${T}_c3_bucket_major_bench.log
 cp gpurun_out/kt/kt_kernel_stats.csv profiles/${T}_c3_bucket_major_kernel_stats.csv
 cp gpurun_out/final_c2.log profiles/${T}_c2_bucket_major_bench.log
 cp gpurun_out/final_c4.log profiles/${T}_c4_bucket_major_bench.log
+cp gpurun_out/final_c5_share.log profiles/${T}_c5_share_bench.log
 cp gpurun_out/final_c3_gather.log profiles/${T}_c3_gather_bench.log
 for s in 0 2 3; do cp gpurun_out/final_c3_s$s.log profiles/${T}_c3_steps${s}_bench.log; done
 cp gpurun_out/final_tests.log profiles/${T}_gpu_tests.log
