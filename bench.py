@@ -39,7 +39,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E peak
 
 
-def workload(name, n, nq):
+def workload(name, n, nq, dim=None):
     from similaritysearchbyrdf_amd import synthetic
     if name == "c2":
         params = synthetic.make_gaussian_family(100, 1, 32, 3, seed=88387, part_seed=88388)
@@ -56,9 +56,10 @@ def workload(name, n, nq):
         X, Q, pick = synthetic.make_sift_like(n, 128, nq)
         steps = 1
     elif name == "c5":
-        params = synthetic.make_family(768, table_num=10, permutation_num=3, chain_length=32, family="angle",
-                                       family_size=768, partition_bits=3, orthogonal=True)
-        X, Q, pick = synthetic.make_unit_gaussian(n, 768, nq)
+        d = dim or 768
+        params = synthetic.make_family(d, table_num=10, permutation_num=3, chain_length=32, family="angle",
+                                       family_size=d, partition_bits=3, orthogonal=True)
+        X, Q, pick = synthetic.make_unit_gaussian(n, d, nq)
         steps = 1
     else:
         raise SystemExit("unknown workload " + name)
@@ -135,6 +136,7 @@ def main():
     ap.add_argument("--workload", default="c3")
     ap.add_argument("--base-rows", dest="n", type=int, default=1_000_000)
     ap.add_argument("--queries", dest="nq", type=int, default=10_000)
+    ap.add_argument("--dim", type=int, default=None, help="c5 only: dimensions of the vectors (default 768)")
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--metric", default="l2", choices=["l2", "dot"])
     ap.add_argument("--search-steps", type=int, default=None)
@@ -167,7 +169,7 @@ def main():
         else:
             dist.init_process_group("gloo")
 
-    params, X, Q, pick, steps = workload(args.workload, args.n, args.nq)
+    params, X, Q, pick, steps = workload(args.workload, args.n, args.nq, args.dim)
     if args.rerank == "gather":
         params["flags"] = 2          # DPF_FLAG_GATHER_ONLY
     if args.search_steps is not None:

@@ -1278,10 +1278,12 @@ __device__ __forceinline__ void leafscan_chunks(const LeafScanParams &p, const u
                                                 uint32_t lq0, float xrm, float cxm, int32_t qsc, int32_t qsn, int32_t *s_fq,
                                                 int32_t *s_fid, float *s_fv, float4 *s_slot, float *s_G, int32_t *s_qid, int &nbuf)
 {
-    static_assert(RB == 4 || RB == 1, "64-row tiles, or 16-row tiles for rows of more than 256 dimensions");
-    // rows longer than 8 steps are scanned 16 at a time (RB == 1): a 64-row tile of them does not fit the
-    // register file; their query rows come in slices of QS steps
-    constexpr int QS = KS > 8 ? 8 : KS;
+    static_assert(RB == 4 || RB == 1, "64-row tiles, or 16-row tiles for rows of more than 768 dimensions");
+    // Rows of more than 8 steps: a 64-row tile still pays (one wave per SIMD holds it in the 512 registers
+    // of its lanes; sharing a tile's rows among 4x the queries outweighs the lost occupancy: 1.4-1.5x
+    // faster than 16-row tiles at 512 and 768 dimensions); beyond 24 steps only 16 rows fit (RB == 1).
+    // Their query rows come in slices of QS steps.
+    constexpr int QS = KS > 8 ? (RB == 4 ? 4 : 8) : KS;
     static_assert(KS % QS == 0, "whole slices");
     const int lane = threadIdx.x & 63;
     const int i16 = lane & 15, g = lane >> 4;
@@ -1480,7 +1482,7 @@ __device__ __forceinline__ void leafscan_flush_rest(const LeafScanParams &p, con
 // first queries) and once per further chunk; the other waves of the SIMD fill those waits.
 // RB*16 rows per tile: 64 measured best on gfx950 (32-row tiles double the per-unit work and
 // were 1.9x slower in spite of the higher occupancy).
-constexpr int ls16_waves(int ks, int rb) { return ks >= 8 ? 2 : LS16_WAVES4; }
+constexpr int ls16_waves(int ks, int rb) { return ks > 8 && rb == 4 ? 1 : ks >= 8 ? 2 : LS16_WAVES4; }
 
 template <int KS, int METRIC, int RB>
 __global__ __launch_bounds__(256, ls16_waves(KS, RB)) void k_leafscan_f16(LeafScanParams p, const uint16_t *__restrict__ Q16,
@@ -1600,14 +1602,12 @@ static void launch_leafscan_f16_m(const LeafScanParams &p, hipStream_t stream)
         case 1: DPF_LB(1); break;
         case 2: DPF_LB(2); break;
         case 4: DPF_LB(4); break;
-        default: DPF_LB(8); break;
+        case 8: DPF_LB(8); break;
+        case 16: DPF_LB(16); break;
+        default: DPF_LB(24); break;
         }
     } else {
-        switch (p.ks) {
-        case 16: DPF_LB(16); break;
-        case 24: DPF_LB(24); break;
-        default: DPF_LB(32); break;
-        }
+        DPF_LB(32);
     }
 #undef DPF_LB
 }
@@ -1807,7 +1807,7 @@ void launch_tau(int metric, const double *seed_scores, const int32_t *seed_ids, 
 
 void launch_leafscan(int metric, const LeafScanParams &p, hipStream_t stream)
 {
-    if (p.ks > 8) {
+    if (leafscan_tile_rows(p.ks) == 16) {
         if (metric == 0) launch_leafscan_f16_m<0, 1>(p, stream);
         else launch_leafscan_f16_m<1, 1>(p, stream);
         return;
@@ -1817,7 +1817,7 @@ void launch_leafscan(int metric, const LeafScanParams &p, hipStream_t stream)
 }
 
 // rows per tile of the scan for rows of `ks` fp16 steps
-int leafscan_tile_rows(int ks) { return ks > 8 ? 16 : 64; }
+int leafscan_tile_rows(int ks) { return ks > 24 ? 16 : 64; }
 
 // flag[0] = number of queries whose forward list overflowed, their indices in list[];
 // flag[2] = the longest forward list of the batch
