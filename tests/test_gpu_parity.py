@@ -314,6 +314,25 @@ def test_full_size_properties():
     assert g2.stats()["misflag_events"] == orc.misflag_events
 
 
+def test_large_forest_batches_in_a_row():
+    # the benchmark's forest shape (30 trees, 1-step search) at 300k rows: batches of changing size through
+    # one handle (sizes carried from batch to batch, regrown once) give the gather path's answers
+    params, X, Q, pick = make_problem(n=300_000, nq=6000, table_num=10, permutation_num=3, n_clusters=300)
+    fast = DpfIndex(params, metric="l2")
+    slow = DpfIndex(dict(params, flags=2), metric="l2")
+    fast.fit(X)
+    slow.fit(X)
+    seen = []
+    for lo, hi in ((0, 4000), (4000, 4500), (0, 4000), (0, 6000), (3000, 6000)):
+        fi, fs = fast.query_topk(pick[lo:hi], Q[lo:hi], steps=1, k=10)
+        st = fast.stats()
+        assert st["last_path"] == 1
+        seen.append(st["last_sizes_carried"])
+        si, ss = slow.query_topk(pick[lo:hi], Q[lo:hi], steps=1, k=10)
+        assert np.array_equal(fi, si) and np.array_equal(fs, ss, equal_nan=True), (lo, hi, seen)
+    assert seen[0] == 0 and seen[1] == 1 and seen[2] == 1 and seen[4] == 1, seen
+
+
 @pytest.mark.parametrize("metric", ["l2", "dot"])
 @pytest.mark.parametrize("dim", [100, 50, 128, 24, 200, 256, 300, 512, 768, 1000])
 def test_bucket_major_rerank_equals_gather_rerank(metric, dim):
