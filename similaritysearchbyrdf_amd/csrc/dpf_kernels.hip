@@ -534,7 +534,7 @@ __global__ __launch_bounds__(1024) void k_probe(ProbeParams p)
 __global__ __launch_bounds__(256) void k_fill_lists(ProbeParams p)
 {
     __shared__ uint32_t s_seed, s_nown;
-    __shared__ uint32_t s_own[256];
+    __shared__ uint32_t s_own[256], s_ob[256], s_oe[256];
     const int64_t q = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (p.abort && *p.abort) {                            // the lists have no room for this batch: it is run again
@@ -576,8 +576,29 @@ __global__ __launch_bounds__(256) void k_fill_lists(ProbeParams p)
     };
     const uint32_t nown = min(s_nown, 256u);
     if (nown > 0) {
+        // all own buckets at once: their bounds in one round of loads, then one thread per (bucket, entry)
         const uint32_t share = ((uint32_t)p.seed_cap + nown - 1u) / nown;
-        for (uint32_t j = wave; j < nown; j += 4) copy_from(s_own[j], share);
+        if ((uint32_t)tid < nown) {
+            const uint32_t leaf = s_own[tid], b = p.leaf_off[leaf], e = p.leaf_off[leaf + 1];
+            s_ob[tid] = b;
+            s_oe[tid] = share < e - b ? b + share : e;
+        }
+        __syncthreads();
+        const uint32_t total = nown * share;
+        for (uint32_t s0 = 0; s0 < total; s0 += 256u) {
+            const uint32_t s = s0 + (uint32_t)tid, j = s / share;
+            const uint32_t k = s < total ? s_ob[j] + (s - j * share) : 0xffffffffu;
+            const bool there = s < total && k < s_oe[j];
+            const int32_t id = there ? p.ids[k] : -1;
+            const bool ok = there && id >= p.row_begin && id < p.row_end && !self_excluded(id, qid, p.exclude_self);
+            const unsigned long long m = __ballot(ok);
+            if (m == 0) continue;
+            uint32_t at0 = 0;
+            if (lane == 0) at0 = atomicAdd(&s_seed, (uint32_t)__popcll(m));
+            at0 = __shfl(at0, 0);
+            const uint32_t at = at0 + __popcll(m & ((1ull << lane) - 1ull));
+            if (ok && at < (uint32_t)p.seed_cap) p.seed_cand[q * p.seed_cap + at] = id;
+        }
     }
     __syncthreads();
     for (int j = wave; j < n && s_seed < (uint32_t)p.seed_cap; j += 4)
