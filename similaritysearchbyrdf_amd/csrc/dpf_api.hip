@@ -917,7 +917,8 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     int32_t *const flags = ix->ws_flag.as<int32_t>();
     int64_t *const d_totals = (int64_t *)((char *)ix->ws_flag.p + 16);
     launch_bucket_scans(ix->ws_lq_cnt.as<uint32_t>(), ix->d_leaf_tile0.as<uint32_t>(), nl, ix->ws_lq_off.as<int64_t>(),
-                        ix->ws_unit_off.as<int64_t>(), d_totals, carried, cap_pairs, cap_units, flags, stream);
+                        ix->ws_unit_off.as<int64_t>(), d_totals, carried, cap_pairs, cap_units, flags,
+                        ix->ws_lq_cursor.as<uint32_t>(), stream);
     int64_t pairs = 0, nunits = 0;
     bool lists_truncated = false;
     if (!carried) {
@@ -971,6 +972,7 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     pp.abort = carried ? flags + 3 : nullptr;
     pp.lq_off = ix->ws_lq_off.as<int64_t>();
     pp.lq_cursor = ix->ws_lq_cursor.as<uint32_t>();
+    pp.lq_off32 = ix->ws_lq_cursor.as<uint32_t>();    // (the second walk, which needs the cursors, does not use these)
     pp.leaf_queries = ix->ws_leaf_queries.as<int32_t>();
     pp.seed_cand = ix->ws_seed_cand.as<int32_t>();
     pp.seed_cnt = ix->ws_seed_cnt.as<int32_t>();

@@ -57,6 +57,7 @@ struct ProbeParams {
     int32_t *cnt;             // [nq] set sizes
     // mode 2 (bucket -> queries lists + per-query seed candidates)
     const int64_t *lq_off;    // [num_leaves + 1] exclusive scan of lq_cnt
+    const uint32_t *lq_off32 = nullptr;   // the same offsets in 32 bits (k_fill_lists: half the gathered table)
     uint32_t *lq_cursor;      // [num_leaves] zeroed
     int32_t *leaf_queries;    // [total pairs]
     int32_t *seed_cand;       // [nq][seed_cap] ids from table 0's buckets
@@ -121,7 +122,8 @@ void launch_fill_lists(const ProbeParams &p, int64_t nq, hipStream_t stream);
 void launch_leafscan(int metric, const LeafScanParams &p, hipStream_t stream);
 // flags[1] != 0 (a truncated bucket list) or a total beyond its capacity sets flags[3] when `guarded`
 void launch_bucket_scans(const uint32_t *lq_cnt, const uint32_t *leaf_tile0, int64_t nl, int64_t *lq_off, int64_t *unit_off,
-                         int64_t *totals, bool guarded, int64_t cap_pairs, int64_t cap_units, int32_t *flags, hipStream_t stream);
+                         int64_t *totals, bool guarded, int64_t cap_pairs, int64_t cap_units, int32_t *flags, uint32_t *lq_off32,
+                         hipStream_t stream);
 void launch_units(const uint32_t *lq_cnt, const int64_t *lq_off, const uint32_t *leaf_tile0, const uint4 *tiles, int64_t ntiles,
                   const int64_t *unit_off, uint4 *units, const int32_t *abort, hipStream_t stream);
 void launch_tile_maxnorm(uint4 *tiles, int64_t ntiles, const int32_t *ids, const float *norms, const float *errs, int64_t row_begin,

@@ -548,7 +548,7 @@ __global__ __launch_bounds__(256) void k_fill_lists(ProbeParams p)
     const uint2 *mine = p.q_leaves + q * p.q_leaf_cap;
     for (int j = tid; j < n; j += 256) {
         const uint2 lp = mine[j];                         // {bucket, place in the bucket's list | own-bucket flag}
-        p.leaf_queries[p.lq_off[lp.x] + (lp.y & 0x7fffffffu)] = (int32_t)q;
+        p.leaf_queries[p.lq_off32[lp.x] + (lp.y & 0x7fffffffu)] = (int32_t)q;
         if (lp.y & 0x80000000u) {
             const uint32_t at = atomicAdd(&s_nown, 1u);
             if (at < 256u) s_own[at] = lp.x;
@@ -1165,7 +1165,8 @@ __global__ __launch_bounds__(1024) void k_scan2_tiles(int64_t n, int64_t ntiles,
 }
 
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan2_apply(const uint32_t *__restrict__ lq_cnt, const uint32_t *__restrict__ leaf_tile0,
-                                                              int64_t n, int64_t *__restrict__ offa, int64_t *__restrict__ offb)
+                                                              int64_t n, int64_t *__restrict__ offa, int64_t *__restrict__ offb,
+                                                              uint32_t *__restrict__ offa32)
 {
     __shared__ int64_t wsa[4], wsb[4];
     const int64_t t0 = (int64_t)blockIdx.x * SCAN_TILE;
@@ -1187,19 +1188,20 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan2_apply(const uint32_t *__
     for (int u = 0; u < w; u++) { ra += wsa[u]; rb += wsb[u]; }
 #pragma unroll
     for (int j = 0; j < SCAN_PER; j++) {
-        if (i0 + j < n) { offa[i0 + j] = ra; offb[i0 + j] = rb; }
+        if (i0 + j < n) { offa[i0 + j] = ra; offb[i0 + j] = rb; offa32[i0 + j] = (uint32_t)ra; }
         ra += va[j]; rb += vb[j];
     }
 }
 
 void launch_bucket_scans(const uint32_t *lq_cnt, const uint32_t *leaf_tile0, int64_t nl, int64_t *lq_off, int64_t *unit_off,
-                         int64_t *totals, bool guarded, int64_t cap_pairs, int64_t cap_units, int32_t *flags, hipStream_t stream)
+                         int64_t *totals, bool guarded, int64_t cap_pairs, int64_t cap_units, int32_t *flags, uint32_t *lq_off32,
+                         hipStream_t stream)
 {
     const int64_t ntiles = (nl + SCAN_TILE - 1) / SCAN_TILE;
     if (ntiles > 0) hipLaunchKernelGGL(k_scan2_sums, dim3((unsigned)ntiles), dim3(SCAN_THREADS), 0, stream, lq_cnt, leaf_tile0, nl, lq_off, unit_off);
     hipLaunchKernelGGL(k_scan2_tiles, dim3(1), dim3(1024), 0, stream, nl, ntiles, lq_off, unit_off, totals, guarded ? 1 : 0,
                        cap_pairs, cap_units, flags);
-    if (ntiles > 0) hipLaunchKernelGGL(k_scan2_apply, dim3((unsigned)ntiles), dim3(SCAN_THREADS), 0, stream, lq_cnt, leaf_tile0, nl, lq_off, unit_off);
+    if (ntiles > 0) hipLaunchKernelGGL(k_scan2_apply, dim3((unsigned)ntiles), dim3(SCAN_THREADS), 0, stream, lq_cnt, leaf_tile0, nl, lq_off, unit_off, lq_off32);
 }
 
 // one thread per tile (a long bucket has thousands of them)
