@@ -159,8 +159,13 @@ void dpf_free(void *p);
 int dpf_query_topk(dpf_index *ix, const int32_t *qids, const void *Q, int64_t nq, int32_t steps,
                    int32_t k, int32_t *ids, double *scores);
 
-/* Same, every buffer already in HBM, enqueued on `stream` (a hipStream_t, NULL =
- * the default stream); returns without synchronising. */
+/* Same, every buffer already in HBM, the kernels enqueued on `stream` (a hipStream_t, NULL =
+ * the default stream).  The call BLOCKS: it waits on `stream` once per batch (twice on a handle's
+ * first bucket-major batch or after a batch outgrew the carried buffers) to read the batch's list
+ * sizes and overflow flags, may grow the handle's workspaces (hipMalloc / hipFree), and runs a batch
+ * again when the buffers carried from earlier batches turn out too small.  On return the last
+ * kernels of the batch (the exact rerank writing d_ids / d_scores) may still be running on `stream`:
+ * order later work on that stream, or synchronise it, before reading the results. */
 int dpf_query_topk_device(dpf_index *ix, const int32_t *d_qids, const void *d_Q, int64_t nq,
                           int32_t steps, int32_t k, int32_t *d_ids, double *d_scores, void *stream);
 
@@ -221,6 +226,20 @@ int dpf_snapshot_copy(dpf_index *ix, uint32_t *roots, uint32_t *dnodes, uint32_t
  * bucket-major path *ms and *algorithmic_bytes are sums over the scan kernel's
  * launches of the batch (dpf_stats.last_scan_launches of them). */
 int dpf_last_rerank_profile(dpf_index *ix, double *ms, int64_t *algorithmic_bytes);
+/* Tuning and test switches of one handle.  None of them changes a result; they choose between paths
+ * that give identical answers (the parity tests pin the paths against each other).  No environment
+ * variable is read by the query path.  value 0 = the library's own choice unless stated. */
+enum {
+    DPF_OPT_EMIT_CAP = 1,            /* entries per forward list of the bucket-major scan, pinned (default: 8192,
+                                        doubled up to 65536 after a batch in which a list overflowed) */
+    DPF_OPT_BUCKET_LIST_CAP = 2,     /* buckets remembered per query by the first probe pass (default: up to 4096) */
+    DPF_OPT_SYNC_SIZES = 3,          /* 1: the host reads every batch's list sizes before filling the lists */
+    DPF_OPT_FIRST_PASS_PERMILLE = 4, /* share of the scan's work units run before the thresholds are refined (100) */
+    DPF_OPT_SEED_SAMPLE = 5,         /* candidates per query scored exactly for the first thresholds (256; 16..4096) */
+    DPF_OPT_SHORT_RERANK = 6         /* 0: short candidate lists use the general rerank kernel too (default 1) */
+};
+int dpf_set_option(dpf_index *ix, int32_t option, int64_t value);
+
 /* enable (1) / disable (0) the per-stage HIP-event timing: the events are recorded only for batches
  * that run while it is on (an event between two kernels costs a few microseconds of stream time);
  * dpf_last_rerank_profile and the last_ms_* statistics need it on for the batch they describe */

@@ -387,16 +387,41 @@ void orc_destroy(orc_index *ix)
     free(ix);
 }
 
+/* The dot products of one chain, sums[j] = orc_dot_dense(function chain[j], v): four functions advance
+ * together so that their four dependent add chains overlap in the pipeline.  Every sum is still its own
+ * strict left-to-right accumulation from 0.0 (product, then add), so each equals orc_dot_dense bit for
+ * bit (checked in tests/test_oracle_kat.py); only the wall-clock time of a fit changes. */
+static void chain_sums(const orc_index *ix, const int32_t *chain, int32_t m, const double *v, double *sums)
+{
+    const int32_t d = ix->cfg.dim;
+    int32_t j = 0;
+    for (; j + 4 <= m; j += 4) {
+        const double *a0 = ix->fns + (int64_t)chain[j] * d, *a1 = ix->fns + (int64_t)chain[j + 1] * d;
+        const double *a2 = ix->fns + (int64_t)chain[j + 2] * d, *a3 = ix->fns + (int64_t)chain[j + 3] * d;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        for (int32_t i = 0; i < d; i++) {
+            const double x = v[i];
+            double p0 = a0[i] * x, p1 = a1[i] * x, p2 = a2[i] * x, p3 = a3[i] * x;
+            s0 = s0 + p0; s1 = s1 + p1; s2 = s2 + p2; s3 = s3 + p3;
+        }
+        sums[j] = s0; sums[j + 1] = s1; sums[j + 2] = s2; sums[j + 3] = s3;
+    }
+    for (; j < m; j++) sums[j] = orc_dot_dense(ix->fns + (int64_t)chain[j] * d, v, d);
+}
+
 /* Hasher:44-54 -> LSH:135-166 -> chain.compute(DenseVector) */
 int32_t orc_hash(const orc_index *ix, int32_t table, const double *v)
 {
     const orc_config *c = &ix->cfg;
     const int32_t *chain = ix->chain_fn + (int64_t)table * c->chain_length;
     int32_t h;
+    double sums_fixed[64];
+    double *sums = c->chain_length <= 64 ? sums_fixed : (double *)malloc(sizeof(double) * (size_t)c->chain_length);
+    chain_sums(ix, chain, c->chain_length, v, sums);
     if (c->family == ORC_FAMILY_ANGLE) {
         int32_t result = 0;
         for (int32_t j = 0; j < c->chain_length; j++) {
-            double s = orc_dot_dense(ix->fns + (int64_t)chain[j] * c->dim, v, c->dim);
+            double s = sums[j];
             result = jshl(result, 1) | orc_angle_sign(s);
         }
         h = jshl(result, 32 - c->chain_length);
@@ -404,7 +429,7 @@ int32_t orc_hash(const orc_index *ix, int32_t table, const double *v)
         uint32_t r = 1;
         for (int32_t j = 0; j < c->chain_length; j++) {
             int32_t f = chain[j];
-            double s = orc_dot_dense(ix->fns + (int64_t)f * c->dim, v, c->dim);
+            double s = sums[j];
             double t = s + ix->b[f];
             t = t / (double)ix->w[f];
             int32_t idx = orc_d2i(t);
@@ -415,6 +440,7 @@ int32_t orc_hash(const orc_index *ix, int32_t table, const double *v)
         }
         h = (int32_t)r;
     }
+    if (sums != sums_fixed) free(sums);
     return apply_type_of_index(ix, h);
 }
 

@@ -44,8 +44,12 @@ EXPORTS = (
     "dpf_set_sampling_index", "dpf_fit", "dpf_hash_batch", "dpf_query_batch", "dpf_free",
     "dpf_query_topk", "dpf_query_topk_device", "dpf_rerank", "dpf_merge_topk_device", "dpf_merge_topk_packed_device",
     "dpf_subindex_distribution", "dpf_get_stats", "dpf_last_rerank_profile", "dpf_set_profiling",
-    "dpf_save", "dpf_load", "dpf_get_config", "dpf_snapshot_sizes", "dpf_snapshot_copy",
+    "dpf_save", "dpf_load", "dpf_get_config", "dpf_snapshot_sizes", "dpf_snapshot_copy", "dpf_set_option",
 )
+
+# dpf_set_option keys (include/dpf.h)
+OPTION = {"emit_cap": 1, "bucket_list_cap": 2, "sync_sizes": 3, "first_pass_permille": 4, "seed_sample": 5,
+          "short_rerank": 6}
 
 _lib = None
 
@@ -104,6 +108,8 @@ def lib():
     L.dpf_last_rerank_profile.argtypes = [vp, dp, i64p]
     L.dpf_set_profiling.restype = C.c_int
     L.dpf_set_profiling.argtypes = [vp, C.c_int32]
+    L.dpf_set_option.restype = C.c_int
+    L.dpf_set_option.argtypes = [vp, C.c_int32, C.c_int64]
     L.dpf_save.restype = C.c_int
     L.dpf_save.argtypes = [vp, C.c_char_p]
     L.dpf_load.restype = C.c_int
@@ -253,7 +259,8 @@ class DpfIndex:
         return ids, sc
 
     def query_topk_device(self, d_qids, d_Q, nq, steps, k, d_ids, d_scores, stream=None):
-        """All arguments are device addresses (ints); asynchronous on `stream`."""
+        """All arguments are device addresses (ints).  Blocking: the call waits on `stream` at least once
+        per batch and may grow workspaces; the final rerank may still be running on `stream` on return."""
         self._check(self.L_.dpf_query_topk_device(self.h, d_qids, d_Q, nq, steps, k, d_ids, d_scores, stream))
 
     def merge_topk_device(self, in_ids, in_scores, parts, nq, k, d_ids, d_scores, stream=None):
@@ -290,6 +297,10 @@ class DpfIndex:
         self._check(self.L_.dpf_snapshot_copy(self.h, roots.ctypes.data, dnodes.ctypes.data, leaf_off.ctypes.data,
                                               ids.ctypes.data))
         return roots, dnodes, leaf_off, ids
+
+    def set_option(self, name, value):
+        """Tuning / test switches of this handle (dpf_set_option); none changes a result."""
+        self._check(self.L_.dpf_set_option(self.h, OPTION[name], int(value)))
 
     def set_profiling(self, on):
         self._check(self.L_.dpf_set_profiling(self.h, 1 if on else 0))

@@ -120,6 +120,9 @@ struct dpf_index {
     int64_t last_nq = 0;
     int32_t last_k = 0;
     bool last_valid = false;
+    // dpf_set_option values (0 / default = the library's own choice)
+    int32_t opt_emit_cap = 0, opt_bucket_list_cap = 0, opt_first_permille = 100, opt_seed_cap = 256;
+    bool opt_sync_sizes = false, opt_short_rerank = true;
 };
 
 #define HIPCHECK(ix, call)                                                              \
@@ -182,7 +185,7 @@ extern "C" int dpf_create(const dpf_config *cfg, dpf_index **out)
     ix->elem = cfg->dtype == DPF_F32 ? 4 : 8;
     const int64_t per16 = 16 / (int64_t)ix->elem;
     ix->dpad = (cfg->dim + per16 - 1) / per16 * per16;
-    if (cfg->dtype == DPF_F32 && !(cfg->flags & DPF_FLAG_GATHER_ONLY) && !getenv("DPF_GATHER_ONLY")) {
+    if (cfg->dtype == DPF_F32 && !(cfg->flags & DPF_FLAG_GATHER_ONLY)) {
         // the bucket-major scan works on fp16 copies of up to 1024 dimensions
         ix->ks16 = leafscan_f16_steps(cfg->dim);
         ix->bucket_major = ix->ks16 > 0;
@@ -752,7 +755,27 @@ static int pad_queries(dpf_index *ix, const void *d_Q, int64_t nq, hipStream_t s
     return DPF_OK;
 }
 
-static void fill_probe_params(dpf_index *ix, ProbeParams &pp, const int32_t *d_qids, int32_t steps)
+// The per-batch buffers of the gather path: the handle's own (grown on demand), or fixed slices of the
+// static scratch array for the entry point that allocates nothing.
+struct ProbeWs {
+    int32_t *hashes = nullptr, *parts = nullptr;     // [nq][L]
+    unsigned long long *raw = nullptr;               // [nq]
+    int64_t *bound = nullptr, *off = nullptr;        // [nq], [nq + 1]
+    int32_t *cnt = nullptr;                          // [nq]
+    int32_t *arena = nullptr;                        // candidate lists
+    int64_t arena_ids = -1;                          // capacity of a fixed arena; < 0: the handle's, grown to fit
+};
+
+static ProbeWs handle_ws(const dpf_index *ix)
+{
+    ProbeWs w;
+    w.hashes = ix->ws_hashes.as<int32_t>(); w.parts = ix->ws_parts.as<int32_t>();
+    w.raw = ix->ws_raw.as<unsigned long long>(); w.bound = ix->ws_bound.as<int64_t>();
+    w.off = ix->ws_off.as<int64_t>(); w.cnt = ix->ws_cnt.as<int32_t>(); w.arena = ix->ws_arena.as<int32_t>();
+    return w;
+}
+
+static void fill_probe_params(dpf_index *ix, ProbeParams &pp, const int32_t *d_qids, int32_t steps, const ProbeWs &w)
 {
     const ForestGeometry &g = ix->geo;
     pp.roots = ix->d_roots.as<uint32_t>();
@@ -765,8 +788,8 @@ static void fill_probe_params(dpf_index *ix, ProbeParams &pp, const int32_t *d_q
     pp.t_begin = ix->cfg.table_begin;
     pp.t_end = ix->cfg.table_end <= 0 ? g.num_tables : ix->cfg.table_end;
     pp.qids = d_qids;
-    pp.hashes = ix->ws_hashes.as<int32_t>();
-    pp.parts = ix->ws_parts.as<int32_t>();
+    pp.hashes = w.hashes;
+    pp.parts = w.parts;
     pp.row_begin = ix->row_begin;
     pp.row_end = std::min<int64_t>(ix->row_end, ix->n);
     if (pp.row_end < pp.row_begin) pp.row_end = pp.row_begin;
@@ -774,47 +797,58 @@ static void fill_probe_params(dpf_index *ix, ProbeParams &pp, const int32_t *d_q
     const int64_t max_words = 32768;                 // 128 KiB bitmap = 2^20 ids per pass
     int64_t words = (range + 31) / 32;
     pp.chunk_words = (int32_t)std::max<int64_t>(1, std::min(words, max_words));
-    pp.raw = ix->ws_raw.as<unsigned long long>();
-    pp.bound = ix->ws_bound.as<int64_t>();
+    pp.raw = w.raw;
+    pp.bound = w.bound;
     pp.short_hash_events = ix->d_short_hash;
-    pp.cand_off = ix->ws_off.as<int64_t>();
-    pp.cand = ix->ws_arena.as<int32_t>();
-    pp.cnt = ix->ws_cnt.as<int32_t>();
+    pp.cand_off = w.off;
+    pp.cand = w.arena;
+    pp.cnt = w.cnt;
     pp.lq_cnt = nullptr; pp.lq_off = nullptr; pp.lq_cursor = nullptr; pp.leaf_queries = nullptr;
     pp.q_leaves = nullptr; pp.q_leaf_cnt = nullptr; pp.q_leaf_cap = 0; pp.q_leaf_overflow = nullptr;
     pp.seed_cand = nullptr; pp.seed_cnt = nullptr; pp.seed_cap = 0;
 }
 
 // hash -> count -> scan -> (sync: arena size) -> dedupe.  Leaves the per-query
-// sets in ws_arena at ws_off[q], sizes in ws_cnt.
+// sets in the arena at off[q], sizes in cnt.  fixed == nullptr: the handle's buffers, grown to fit;
+// otherwise the given buffers, and a batch whose lists do not fit the arena is refused.
 static int run_probe(dpf_index *ix, const int32_t *d_qids, const void *d_Qpad, int64_t q_stride, int64_t nq,
-                     int32_t steps, hipStream_t stream)
+                     int32_t steps, hipStream_t stream, const ProbeWs *fixed = nullptr)
 {
     const int L = ix->cfg.num_tables;
-    HIPCHECK(ix, ix->ws_hashes.ensure((size_t)nq * L * 4));
-    HIPCHECK(ix, ix->ws_parts.ensure((size_t)nq * L * 4));
-    HIPCHECK(ix, ix->ws_raw.ensure((size_t)nq * 8));
-    HIPCHECK(ix, ix->ws_bound.ensure((size_t)nq * 8));
-    HIPCHECK(ix, ix->ws_off.ensure((size_t)(nq + 1) * 8));
-    HIPCHECK(ix, ix->ws_cnt.ensure((size_t)nq * 4));
+    if (!fixed) {
+        HIPCHECK(ix, ix->ws_hashes.ensure((size_t)nq * L * 4));
+        HIPCHECK(ix, ix->ws_parts.ensure((size_t)nq * L * 4));
+        HIPCHECK(ix, ix->ws_raw.ensure((size_t)nq * 8));
+        HIPCHECK(ix, ix->ws_bound.ensure((size_t)nq * 8));
+        HIPCHECK(ix, ix->ws_off.ensure((size_t)(nq + 1) * 8));
+        HIPCHECK(ix, ix->ws_cnt.ensure((size_t)nq * 4));
+    }
+    ProbeWs w = fixed ? *fixed : handle_ws(ix);
     if (ix->profiling) HIPCHECK(ix, hipEventRecord(ix->ev[0], stream));
-    launch_hash(ix->cfg.dtype, d_Qpad, q_stride, nq, ix->hp, ix->ws_hashes.as<int32_t>(), ix->ws_parts.as<int32_t>(), stream);
+    launch_hash(ix->cfg.dtype, d_Qpad, q_stride, nq, ix->hp, w.hashes, w.parts, stream);
     if (ix->profiling) HIPCHECK(ix, hipEventRecord(ix->ev[1], stream));
     ProbeParams pp;
-    fill_probe_params(ix, pp, d_qids, steps);
+    fill_probe_params(ix, pp, d_qids, steps, w);
     launch_probe(0, pp, nq, stream);
-    launch_scan_i64(pp.bound, nq, ix->ws_off.as<int64_t>(), stream);
-    HIPCHECK(ix, hipMemcpyAsync(ix->pinned, ix->ws_off.as<int64_t>() + nq, 8, hipMemcpyDeviceToHost, stream));
+    launch_scan_i64(pp.bound, nq, w.off, stream);
+    HIPCHECK(ix, hipMemcpyAsync(ix->pinned, w.off + nq, 8, hipMemcpyDeviceToHost, stream));
     HIPCHECK(ix, hipStreamSynchronize(stream));
     const int64_t total = ix->pinned[0];
-    HIPCHECK(ix, ix->ws_arena.ensure((size_t)std::max<int64_t>(total, 1) * 4));
-    fill_probe_params(ix, pp, d_qids, steps);
+    if (fixed) {
+        if (total > fixed->arena_ids)
+            return fail(ix, DPF_ECAPACITY, "the batch's candidate lists (" + std::to_string(total) + " ids) exceed the static scratch arena (" +
+                                           std::to_string(fixed->arena_ids) + " ids): use fewer queries per call, or dpf_query_topk_device");
+    } else {
+        HIPCHECK(ix, ix->ws_arena.ensure((size_t)std::max<int64_t>(total, 1) * 4));
+        w = handle_ws(ix);
+    }
+    fill_probe_params(ix, pp, d_qids, steps, w);
     if (ix->profiling) HIPCHECK(ix, hipEventRecord(ix->ev[2], stream));
     launch_probe(1, pp, nq, stream);
     if (ix->profiling) HIPCHECK(ix, hipEventRecord(ix->ev[3], stream));
     HIPCHECK(ix, hipGetLastError());
     ix->last_nq = nq;
-    ix->last_valid = true;
+    ix->last_valid = !fixed;          // the statistics read the handle's own buffers
     return DPF_OK;
 }
 
@@ -841,17 +875,10 @@ static const int TICKET_COUNTERS = 16;
 static const size_t FLAG_BYTES = 128 + 2 * (size_t)TICKET_COUNTERS * 128;
 // the per-query forward counts sit behind them, so that one memset clears everything a batch starts from
 static int32_t *emit_cnt_of(const dpf_index *ix) { return (int32_t *)((char *)ix->ws_flag.p + FLAG_BYTES); }
-static const int32_t SEED_CAP = getenv("DPF_SEED_CAP") ? atoi(getenv("DPF_SEED_CAP")) : 256;     // seed sample per query
 // Forwarded candidates a query's list holds before the gather path answers the query instead.  The
 // handle starts at 8192 and doubles the lists (up to 65536) after a batch in which a list overflowed;
-// DPF_EMIT_CAP pins the value (tests).
-static int32_t emit_cap_setting(const dpf_index *ix)
-{
-    const char *e = getenv("DPF_EMIT_CAP");
-    if (!e) return ix->emit_cap;
-    const int v = atoi(e);
-    return v < 1 ? 1 : v;
-}
+// DPF_OPT_EMIT_CAP pins the value.
+static int32_t emit_cap_setting(const dpf_index *ix) { return ix->opt_emit_cap > 0 ? ix->opt_emit_cap : ix->emit_cap; }
 
 // Bucket-major rerank: hash -> count + (query, bucket) histogram -> scan -> bucket->queries lists
 // + seed lists -> exact top-k of the seeds (thresholds) -> bucket-major fp32 filter -> exact
@@ -862,6 +889,7 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
 {
     *done = false;
     const int32_t EMIT_CAP = emit_cap_setting(ix);
+    const int32_t SEED_CAP = ix->opt_seed_cap;            // seed sample per query
     const int L = ix->cfg.num_tables;
     const int64_t nl = ix->num_leaves;
     HIPCHECK(ix, ix->ws_hashes.ensure((size_t)nq * L * 4));
@@ -888,7 +916,7 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     HIPCHECK(ix, hipMemsetAsync(ix->ws_lq_cnt.p, 0, lq_cnt_bytes, stream));
     HIPCHECK(ix, hipMemsetAsync(ix->ws_flag.p, 0, flag_bytes, stream));
     ProbeParams pp;
-    fill_probe_params(ix, pp, d_qids, steps);
+    fill_probe_params(ix, pp, d_qids, steps, handle_ws(ix));
     pp.lq_cnt = ix->ws_lq_cnt.as<uint32_t>();
     // the buckets each query reaches are remembered (up to a cap) so that the lists can be filled
     // without walking the forest again
@@ -897,7 +925,7 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
         for (int s2 = 0; s2 < ix->geo.num_parts; s2++) nsub += __builtin_popcount((unsigned)s2) <= steps;
         const int64_t most = (int64_t)L * 28 * nsub;          // every probe in a bucket of its own
         pp.q_leaf_cap = (int32_t)std::min<int64_t>(most, 4096);
-        if (const char *e = getenv("DPF_Q_LEAF_CAP")) pp.q_leaf_cap = std::max(1, atoi(e));   // tests: force truncation
+        if (ix->opt_bucket_list_cap > 0) pp.q_leaf_cap = ix->opt_bucket_list_cap;
         HIPCHECK(ix, ix->ws_q_leaves.ensure((size_t)nq * pp.q_leaf_cap * 8));
         HIPCHECK(ix, ix->ws_q_leaf_cnt.ensure((size_t)nq * 4));
         pp.q_leaves = ix->ws_q_leaves.as<uint2>();
@@ -910,8 +938,7 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     // batch of a handle reads them back here; later batches do not wait: the kernels behind this point take the
     // totals from device memory, the buffers keep the headroom earlier batches left them, and a batch that
     // outgrows them (or truncated a bucket list) raises a flag, writes nothing and is run again the slow way.
-    static const bool no_carry = getenv("DPF_SYNC_SIZES") != nullptr;
-    const bool carried = ix->sizes_carried && !no_carry && !getenv("DPF_DEBUG");
+    const bool carried = ix->sizes_carried && !ix->opt_sync_sizes;
     const int64_t cap_pairs = std::min<int64_t>((int64_t)(ix->ws_leaf_queries.cap / 4), 0xfffffffell);
     const int64_t cap_units = std::min<int64_t>((int64_t)(ix->ws_units.cap / 16), 0xfffffffell);
     int32_t *const flags = ix->ws_flag.as<int32_t>();
@@ -928,45 +955,6 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
         lists_truncated = (int32_t)((uint64_t)ix->pinned[0] >> 32) != 0;
         // unit descriptors index leaf_queries[] and the unit list with 32 bits
         if (pairs >= (int64_t)0xffffffffll || nunits >= (int64_t)0xffffffffll) return DPF_OK;
-    }
-    if (getenv("DPF_DEBUG")) {
-        std::vector<uint32_t> c((size_t)nl);
-        HIPCHECK(ix, hipMemcpy(c.data(), ix->ws_lq_cnt.p, (size_t)nl * 4, hipMemcpyDeviceToHost));
-        std::vector<uint32_t> srt(c);
-        std::sort(srt.begin(), srt.end());
-        size_t touched = 0;
-        for (auto v : c) touched += v > 0;
-        size_t ttiles = 0, iters = 0, blocks16 = 0;
-        double useful = 0;
-        for (size_t l = 0; l < c.size(); l++) if (c[l]) {
-            const size_t len = ix->h_leaf_len[l], t = (len + 63) / 64, ch = (c[l] + 15) / 16;
-            ttiles += t;
-            iters += t * ch;
-            blocks16 += ((len + 15) / 16) * ch;
-            useful += (double)len * c[l];
-        }
-        fprintf(stderr, "[dpf] tiles %lld touched %zu units %lld; (tile, 16-query chunk) iterations %zu, 16x16 blocks %zu, scores needed %.3g = %.2f of the blocks\n",
-                (long long)ix->ntiles, ttiles, (long long)nunits, iters, blocks16, useful, useful / ((double)blocks16 * 256.0));
-        {   // how evenly the static striding of the scan spreads the work (cost model: 1 per unit + 1 per chunk)
-            const size_t W = (size_t)ix->num_cus * 3 * 4;
-            std::vector<double> load(W, 0.0);
-            size_t u = 0;
-            double total_cost = 0;
-            for (size_t l = 0; l < c.size(); l++) if (c[l]) {
-                const size_t t = (ix->h_leaf_len[l] + 63) / 64;
-                for (size_t ti = 0; ti < t; ti++)
-                    for (uint32_t q0 = 0; q0 < c[l]; q0 += 128, u++) {
-                        const double cost = 1.0 + (double)((std::min<uint32_t>(128u, c[l] - q0) + 15) / 16);
-                        load[u % W] += cost;
-                        total_cost += cost;
-                    }
-            }
-            const double mx = *std::max_element(load.begin(), load.end());
-            fprintf(stderr, "[dpf] static striding over %zu waves: busiest wave %.3f x the mean\n", W, mx / (total_cost / (double)W));
-        }
-        fprintf(stderr, "[dpf] buckets %lld touched %zu pairs %lld queries/bucket: median %u p90 %u p99 %u p999 %u max %u\n",
-                (long long)nl, touched, (long long)pairs, srt[srt.size() / 2], srt[srt.size() * 9 / 10],
-                srt[srt.size() * 99 / 100], srt[srt.size() * 999 / 1000], srt.back());
     }
     if (!carried) HIPCHECK(ix, ix->ws_leaf_queries.ensure((size_t)std::max<int64_t>(pairs + pairs / 2, 1024) * 4));
     pp.abort = carried ? flags + 3 : nullptr;
@@ -989,7 +977,7 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     fill_rerank_params(ix, rp, qpad, k, nullptr, ix->ws_seed_cnt.as<int32_t>(), ix->ws_seed_cand.as<int32_t>(),
                        ix->ws_seed_ids.as<int32_t>(), ix->ws_seed_scores.as<double>());
     rp.cand_stride = SEED_CAP;
-    static const bool short_lists = !getenv("DPF_NO_SHORT_RERANK");
+    const bool short_lists = ix->opt_short_rerank;
     if (short_lists && rerank_short_applies(rp)) launch_rerank_short(ix->cfg.dtype, ix->cfg.metric, rp, nq, stream);
     else launch_rerank(ix->cfg.dtype, ix->cfg.metric, rp, nq, stream);
 
@@ -1016,7 +1004,7 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     lp.k = k;
     lp.emit = ix->ws_emit.as<int32_t>(); lp.emit_v = ix->ws_emit_v.as<float>();
     lp.emit_cnt = emit_cnt_of(ix); lp.emit_cap = EMIT_CAP;
-    lp.debug = getenv("DPF_LS_DEBUG") ? atoi(getenv("DPF_LS_DEBUG")) : 0;
+    lp.debug = 0;
     lp.Q16 = ix->ws_q16.as<uint16_t>(); lp.base16 = ix->d_base16.as<uint16_t>();
     lp.slot_norm = ix->d_slot_norm.as<float>(); lp.qc = (const float4 *)ix->ws_qc.p;
     lp.units = (const uint4 *)ix->ws_units.p;
@@ -1024,7 +1012,7 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     lp.num_counters = TICKET_COUNTERS;
     lp.tickets = (unsigned int *)((char *)ix->ws_flag.p + 128);
     // a first slice of the units, then thresholds refined from what it forwarded, then the rest
-    static const int first_permille = getenv("DPF_FIRST_PASS") ? atoi(getenv("DPF_FIRST_PASS")) : 100;
+    const int first_permille = ix->opt_first_permille;
     int64_t n_first = std::min<int64_t>(nunits, nunits * first_permille / 1000);
     if (carried) { lp.totals = d_totals; lp.abort = flags + 3; lp.first_permille = first_permille; }
     lp.pass = 0;
@@ -1058,19 +1046,12 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     ix->sizes_carried = !lists_truncated;
     ix->scan_launches = n_first > 0 ? 2 : 1;
     ix->st.last_pairs = pairs;
-    if (getenv("DPF_DEBUG")) {
-        std::vector<int32_t> c((size_t)nq);
-        HIPCHECK(ix, hipMemcpy(c.data(), (void *)emit_cnt_of(ix), (size_t)nq * 4, hipMemcpyDeviceToHost));
-        std::sort(c.begin(), c.end());
-        fprintf(stderr, "[dpf] forwarded per query: median %d p90 %d p99 %d max %d (cap %d)\n", c[c.size() / 2],
-                c[c.size() * 9 / 10], c[c.size() * 99 / 100], c.back(), EMIT_CAP);
-    }
     // Queries whose forward list overflowed are answered by the gather path afterwards, as a batch of
     // their own; when they are many the whole batch goes that way.
     const int64_t n_ovf = (int32_t)(ix->pinned[4] & 0xffffffff);
     const int32_t longest = (int32_t)(ix->pinned[5] & 0xffffffff);
     ix->st.last_overflowed = n_ovf;
-    if (n_ovf > 0 && !getenv("DPF_EMIT_CAP") && ix->emit_cap < 65536) ix->emit_cap *= 2;   // from the next batch on
+    if (n_ovf > 0 && ix->opt_emit_cap <= 0 && ix->emit_cap < 65536) ix->emit_cap *= 2;   // from the next batch on
     if (n_ovf * 8 > nq) return DPF_OK;
 
     // distinct ids of every forward list (a row is forwarded once per tree it was found in)
@@ -1308,6 +1289,37 @@ extern "C" int dpf_merge_topk_packed_device(dpf_index *ix, const void *in, int64
     launch_merge_topk(ix->cfg.metric, ids, scores, parts, part_bytes / 4, part_bytes / 8, nq, k, d_ids, d_scores, (hipStream_t)stream);
     HIPCHECK(ix, hipGetLastError());
     return DPF_OK;
+}
+
+extern "C" int dpf_set_option(dpf_index *ix, int32_t option, int64_t value)
+{
+    if (!ix) return DPF_EINVAL;
+    switch (option) {
+    case DPF_OPT_EMIT_CAP:
+        if (value < 0 || value > 65536) return fail(ix, DPF_EINVAL, "dpf_set_option: forward-list capacity must be in [0, 65536]");
+        ix->opt_emit_cap = (int32_t)value;
+        return DPF_OK;
+    case DPF_OPT_BUCKET_LIST_CAP:
+        if (value < 0 || value > 4096) return fail(ix, DPF_EINVAL, "dpf_set_option: bucket-list capacity must be in [0, 4096]");
+        ix->opt_bucket_list_cap = (int32_t)value;
+        return DPF_OK;
+    case DPF_OPT_SYNC_SIZES:
+        ix->opt_sync_sizes = value != 0;
+        return DPF_OK;
+    case DPF_OPT_FIRST_PASS_PERMILLE:
+        if (value < 0 || value > 1000) return fail(ix, DPF_EINVAL, "dpf_set_option: first-pass share must be in [0, 1000]");
+        ix->opt_first_permille = (int32_t)value;
+        return DPF_OK;
+    case DPF_OPT_SEED_SAMPLE:
+        if (value < 16 || value > 4096) return fail(ix, DPF_EINVAL, "dpf_set_option: seed sample must be in [16, 4096]");
+        ix->opt_seed_cap = (int32_t)value;
+        return DPF_OK;
+    case DPF_OPT_SHORT_RERANK:
+        ix->opt_short_rerank = value != 0;
+        return DPF_OK;
+    default:
+        return fail(ix, DPF_EINVAL, "dpf_set_option: unknown option");
+    }
 }
 
 extern "C" int dpf_set_profiling(dpf_index *ix, int32_t on)

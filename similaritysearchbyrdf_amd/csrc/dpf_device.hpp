@@ -81,7 +81,7 @@ struct LeafScanParams {
     float *emit_v;               // [nq][emit_cap] pessimistic score bound of each forwarded row
     int32_t *emit_cnt;           // [nq] may exceed emit_cap: overflow
     int32_t emit_cap;
-    int32_t debug;               // ablation switch for measurements (0 in production)
+    int32_t debug;               // ablation bits, honoured only by kernels built with -DDPF_ABLATE
     const uint16_t *Q16;         // fp16 copies: queries [nq][ks*32], rows [rows][ks*32]
     const uint16_t *base16;
     const float *slot_norm;      // squared norms of the fp16 copies (fp32 sums), in bucket order beside ids[]

@@ -1263,6 +1263,14 @@ void launch_tile_maxnorm(uint4 *tiles, int64_t ntiles, const int32_t *ids, const
     if (ntiles > 0) hipLaunchKernelGGL(k_tile_maxnorm, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, stream, tiles, ntiles, ids, norms, errs, row_begin, row_end, slot_norms);
 }
 
+// Ablation switches of the scan (timing experiments that give wrong answers on purpose) exist only in
+// builds made with -DDPF_ABLATE; the shipped kernel has none.
+#ifdef DPF_ABLATE
+#define DPF_ABLATION(p, bit) (((p).debug & (bit)) != 0)
+#else
+#define DPF_ABLATION(p, bit) false
+#endif
+
 // Rounding allowance of the filter, per unit of |q~|^2 + |x~|^2: fp32 accumulation of K products on
 // top of the row's share of the threshold (the accumulator starts at -J), the fp32 sums behind the
 // two norms, and the roundings of the threshold arithmetic.
@@ -1327,7 +1335,7 @@ __device__ __forceinline__ void leafscan_chunks(const LeafScanParams &p, const u
     for (uint32_t c = 0; c < nq; c += 16u) {
         f16x8 qa[QS];
         const size_t qat = (size_t)(qsc >= 0 ? qsc : 0);
-        const uint16_t *qrow = Q16 + ((p.debug & 2) ? (qat & 15) : qat) * STRIDE + 8 * g;   // debug 2: all query rows from one hot spot (timing only)
+        const uint16_t *qrow = Q16 + (DPF_ABLATION(p, 2) ? (qat & 15) : qat) * STRIDE + 8 * g;   // debug 2: all query rows from one hot spot (timing only)
 #pragma unroll
         for (int t = 0; t < QS; t++) qa[t] = *(const f16x8 *)(qrow + 32 * t);
         const float m_tau = dec_f32(__hip_atomic_load(&p.tau[qat], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
@@ -1384,7 +1392,7 @@ __device__ __forceinline__ void leafscan_chunks(const LeafScanParams &p, const u
             }
         }
         // lane l holds d = q~(MFMA row 4g + r) . x~(rb*16 + i16) - J in acc[rb][r]
-        if (p.debug & 1) {                            // ablation runs: loads and products only
+        if (DPF_ABLATION(p, 1)) {                            // ablation runs: loads and products only
             float t = 0.f;
 #pragma unroll
             for (int rb = 0; rb < RB; rb++) t += acc[rb][rb];
@@ -1449,7 +1457,7 @@ __device__ __forceinline__ void leafscan_chunks(const LeafScanParams &p, const u
                     }
                 }
             }
-            if (METRIC == 1 && tight >= p.k && !(p.debug & 4)) {
+            if (METRIC == 1 && tight >= p.k && !DPF_ABLATION(p, 4)) {
                 // Roughly k or more rows of this tile sit inside 0.985 of the k-th best distance.  With
                 //   v = sqrt(s_hi) + |x - x~|max >= sqrt(exact distance) - |q - q~|
                 // the k-th smallest v among the RB*16 rows this 16-lane group holds for the query bounds

@@ -159,7 +159,9 @@ class ShardedDpf:
         self.index.fit(X)
 
     def query_topk(self, d_qids, d_Q, steps, k, out_ids, out_scores, stream=None):
-        """Device tensors in, merged device tensors out (asynchronous on `stream`)."""
+        """Device tensors in, merged device tensors out.  `stream` must be torch's current stream (the
+        collective and the copies below are ordered on that one); the device stage blocks the host once
+        per batch (dpf_query_topk_device), the results are complete once `stream` has drained."""
         import torch
         nq = d_Q.shape[0]
         if self.world == 1:

@@ -361,13 +361,13 @@ def test_bucket_major_rerank_equals_gather_rerank(metric, dim):
     assert st["last_pairs"] > 0 and 0 < st["last_forwarded"] <= st["last_raw_candidates"]
 
 
-def test_bucket_major_overflow_falls_back_to_gather(monkeypatch):
+def test_bucket_major_overflow_falls_back_to_gather():
     params, X, Q, pick = make_problem(n=8000, nq=40, bucket_overflow=60, n_clusters=6)
     slow = DpfIndex(dict(params, flags=2), metric="l2")
     slow.fit(X)
     want = slow.query_topk(pick, Q, steps=1, k=10)
-    monkeypatch.setenv("DPF_EMIT_CAP", "4")      # any query forwarding more than 4 candidates overflows
     fast = DpfIndex(params, metric="l2")
+    fast.set_option("emit_cap", 4)               # any query forwarding more than 4 candidates overflows
     fast.fit(X)
     got = fast.query_topk(pick, Q, steps=1, k=10)
     assert fast.stats()["last_path"] == 0
@@ -478,7 +478,7 @@ def test_list_sizes_carried_from_batch_to_batch(metric):
 
 
 @pytest.mark.gpu
-def test_carried_sizes_with_a_truncated_bucket_list(monkeypatch):
+def test_carried_sizes_with_a_truncated_bucket_list():
     # a batch that did not wait for its sizes and then truncates a query's bucket list is run again
     # with the second walk
     params, X, Q, pick = make_problem(n=8000, nq=60, bucket_overflow=60, n_clusters=6, table_num=2, permutation_num=1)
@@ -489,7 +489,7 @@ def test_carried_sizes_with_a_truncated_bucket_list(monkeypatch):
     seen = []
     for i, steps in enumerate((1, 1, 1, 1, 0)):
         if i == 2:
-            monkeypatch.setenv("DPF_Q_LEAF_CAP", "3")     # read at every batch
+            fast.set_option("bucket_list_cap", 3)
         got = fast.query_topk(pick, Q, steps=steps, k=10)
         st = fast.stats()
         assert st["last_path"] == 1
@@ -500,15 +500,15 @@ def test_carried_sizes_with_a_truncated_bucket_list(monkeypatch):
 
 
 @pytest.mark.gpu
-def test_bucket_major_truncated_bucket_lists_walk_again(monkeypatch):
+def test_bucket_major_truncated_bucket_lists_walk_again():
     # the first probe pass remembers each query's buckets up to a cap; past it the lists are
     # filled by a second walk.  Same answer either way.
     params, X, Q, pick = make_problem(n=8000, nq=60, bucket_overflow=60, n_clusters=6)
     slow = DpfIndex(dict(params, flags=2), metric="l2")
     slow.fit(X)
     want = slow.query_topk(pick, Q, steps=1, k=10)
-    monkeypatch.setenv("DPF_Q_LEAF_CAP", "3")
     fast = DpfIndex(params, metric="l2")
+    fast.set_option("bucket_list_cap", 3)
     fast.fit(X)
     got = fast.query_topk(pick, Q, steps=1, k=10)
     assert fast.stats()["last_path"] == 1
@@ -695,7 +695,7 @@ def test_device_forest_degenerate_inputs():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("metric,with_qids", [("l2", True), ("l2", False), ("dot", True)])
-def test_overflowed_queries_take_the_gather_path_alone(monkeypatch, metric, with_qids):
+def test_overflowed_queries_take_the_gather_path_alone(metric, with_qids):
     # a forward-list cap that only a few queries exceed: those are answered by the gather path as a
     # batch of their own, the others by the scan, and the batch equals the gather-only handle's
     params, X, Q, pick = make_problem(n=12000, nq=400, bucket_overflow=60, n_clusters=8)
@@ -705,8 +705,8 @@ def test_overflowed_queries_take_the_gather_path_alone(monkeypatch, metric, with
     want = slow.query_topk(qids, Q, steps=1, k=10)
     seen_partial = False
     for cap in (512, 256, 128, 96, 64, 48, 32, 24, 16):
-        monkeypatch.setenv("DPF_EMIT_CAP", str(cap))
         fast = DpfIndex(params, metric=metric)
+        fast.set_option("emit_cap", cap)
         fast.fit(X)
         got = fast.query_topk(qids, Q, steps=1, k=10)
         st = fast.stats()

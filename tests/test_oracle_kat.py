@@ -234,3 +234,29 @@ def test_angle_new_method_thresholds_have_margin():
         assert min(abs(a - t) for t in th) > 1e-6
     assert np.isnan(L.orc_angle_distance(0))
     assert L.orc_angle_new_method(0) == 0
+
+
+@pytest.mark.parametrize("family", ["angle", "pStable"])
+@pytest.mark.parametrize("dim", [3, 100, 257])
+def test_index_hash_equals_the_pinned_chain_functions(family, dim):
+    # OracleIndex.hash evaluates a chain's dot products four at a time; every sum is still its own
+    # left-to-right accumulation, so it must equal the stand-alone chain functions the known-answer
+    # tests above pin (AngleHashSuite.scala:17,32, PStableHashSuite.scala:24,40), bit for bit
+    from similaritysearchbyrdf_amd import synthetic
+    rng = np.random.default_rng(dim)
+    kw = dict(table_num=3, permutation_num=2) if family == "angle" else dict(table_num=4, permutation_num=1)
+    params = synthetic.make_family(dim, chain_length=32, family=family, family_size=max(dim, 40), partition_bits=2,
+                                   pstable_w=3, seed=5, part_seed=6, **kw)
+    orc = O.OracleIndex(params)
+    X = rng.normal(size=(40, dim)) * 3.0
+    for t in range(orc.L):
+        fns = np.ascontiguousarray(orc.fns[orc.chain_fn[t]])
+        for v in X:
+            v = np.ascontiguousarray(v)
+            if family == "angle":
+                want = L.orc_angle_hash_dense(dp(fns), 32, dim, dp(v))
+            else:
+                b = np.ascontiguousarray(orc.b[orc.chain_fn[t]])
+                w = np.ascontiguousarray(orc.w[orc.chain_fn[t]])
+                want = L.orc_pstable_hash_dense(dp(fns), dp(b), ip(w), 32, dim, dp(v))
+            assert orc.hash(t, v) == want
