@@ -169,6 +169,19 @@ int dpf_query_topk(dpf_index *ix, const int32_t *qids, const void *Q, int64_t nq
 int dpf_query_topk_device(dpf_index *ix, const int32_t *d_qids, const void *d_Q, int64_t nq,
                           int32_t steps, int32_t k, int32_t *d_ids, double *d_scores, void *stream);
 
+/* dpf_query_topk_device for callers that cannot allocate device memory (code under HIP graph
+ * capture rules, tight serving loops, harnesses that forbid hipMalloc).  It has no counterpart in
+ * the reference.  Same arguments, same results bit for bit (it takes the per-query gather path:
+ * candidate Set, exact fp64 scores), but every per-batch buffer - padded query rows, hashes,
+ * sub-indexes, counts, offsets, the candidate lists - is a fixed slice of one 29 MiB array in the
+ * library's device image, and the call makes no hipMalloc / hipFree.  Limits per call, refused with
+ * DPF_ECAPACITY beyond them: 1024 queries, 4 MiB of padded query rows, 131072 (query, table) pairs,
+ * and 6 291 456 candidate ids over all queries of the call (counted per query as min(ids visited,
+ * rows in the shard)).  The call waits on `stream` once (to read that total).  All handles on one GPU
+ * share that GPU's array: calls that overlap on one GPU race. */
+int dpf_query_topk_device_static(dpf_index *ix, const int32_t *d_qids, const void *d_Q, int64_t nq,
+                                 int32_t steps, int32_t k, int32_t *d_ids, double *d_scores, void *stream);
+
 /* Dense:477-505 alone: rerank caller-supplied candidate lists (host pointers). */
 int dpf_rerank(dpf_index *ix, const void *Q, int64_t nq, const int64_t *cand_offsets,
                const int32_t *cand_ids, int32_t k, int32_t *ids, double *scores);

@@ -44,7 +44,7 @@ EXPORTS = (
     "dpf_set_sampling_index", "dpf_fit", "dpf_hash_batch", "dpf_query_batch", "dpf_free",
     "dpf_query_topk", "dpf_query_topk_device", "dpf_rerank", "dpf_merge_topk_device", "dpf_merge_topk_packed_device",
     "dpf_subindex_distribution", "dpf_get_stats", "dpf_last_rerank_profile", "dpf_set_profiling",
-    "dpf_save", "dpf_load", "dpf_get_config", "dpf_snapshot_sizes", "dpf_snapshot_copy", "dpf_set_option",
+    "dpf_save", "dpf_load", "dpf_get_config", "dpf_snapshot_sizes", "dpf_snapshot_copy", "dpf_set_option", "dpf_query_topk_device_static",
 )
 
 # dpf_set_option keys (include/dpf.h)
@@ -94,6 +94,8 @@ def lib():
     L.dpf_query_topk.argtypes = [vp, ip, vp, C.c_int64, C.c_int32, C.c_int32, ip, dp]
     L.dpf_query_topk_device.restype = C.c_int
     L.dpf_query_topk_device.argtypes = [vp, vp, vp, C.c_int64, C.c_int32, C.c_int32, vp, vp, vp]
+    L.dpf_query_topk_device_static.restype = C.c_int
+    L.dpf_query_topk_device_static.argtypes = [vp, vp, vp, C.c_int64, C.c_int32, C.c_int32, vp, vp, vp]
     L.dpf_rerank.restype = C.c_int
     L.dpf_rerank.argtypes = [vp, vp, C.c_int64, i64p, ip, C.c_int32, ip, dp]
     L.dpf_merge_topk_device.restype = C.c_int
@@ -262,6 +264,10 @@ class DpfIndex:
         """All arguments are device addresses (ints).  Blocking: the call waits on `stream` at least once
         per batch and may grow workspaces; the final rerank may still be running on `stream` on return."""
         self._check(self.L_.dpf_query_topk_device(self.h, d_qids, d_Q, nq, steps, k, d_ids, d_scores, stream))
+
+    def query_topk_device_static(self, d_qids, d_Q, nq, steps, k, d_ids, d_scores, stream=None):
+        """query_topk_device through the entry point that allocates nothing (fixed scratch, limited batch)."""
+        self._check(self.L_.dpf_query_topk_device_static(self.h, d_qids, d_Q, nq, steps, k, d_ids, d_scores, stream))
 
     def merge_topk_device(self, in_ids, in_scores, parts, nq, k, d_ids, d_scores, stream=None):
         self._check(self.L_.dpf_merge_topk_device(self.h, in_ids, in_scores, parts, nq, k, d_ids, d_scores, stream))

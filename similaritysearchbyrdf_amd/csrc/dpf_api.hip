@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -22,6 +23,52 @@ using namespace dpf;
 namespace {
 
 std::string g_create_error;
+
+// ---------------------------------------------------------------------------
+// The scratch of dpf_query_topk_device_static, the entry point that allocates nothing: one array per GPU
+// in the library's device image (each GPU the process touches holds its copy until the process ends).
+// Host code never uses the array's name as an address: dpf_create asks the runtime once per device where
+// that device's copy lives (scratch_of) and everything below works with that pointer.
+// ---------------------------------------------------------------------------
+constexpr size_t SCRATCH_MAX_QUERIES = 1024;                       // queries per call
+constexpr size_t SCRATCH_QPAD_BYTES = (size_t)4 << 20;             // padded query rows
+constexpr size_t SCRATCH_HASH_WORDS = (size_t)128 << 10;           // nq * num_tables, hashes and sub-indexes each
+constexpr size_t SCRATCH_ARENA_IDS = (size_t)6 << 20;              // candidate lists of the whole call
+constexpr size_t SCRATCH_OFF_QPAD = 0;
+constexpr size_t SCRATCH_OFF_HASHES = SCRATCH_OFF_QPAD + SCRATCH_QPAD_BYTES;
+constexpr size_t SCRATCH_OFF_PARTS = SCRATCH_OFF_HASHES + SCRATCH_HASH_WORDS * 4;
+constexpr size_t SCRATCH_OFF_RAW = SCRATCH_OFF_PARTS + SCRATCH_HASH_WORDS * 4;
+constexpr size_t SCRATCH_OFF_BOUND = SCRATCH_OFF_RAW + SCRATCH_MAX_QUERIES * 8;
+constexpr size_t SCRATCH_OFF_OFF = SCRATCH_OFF_BOUND + SCRATCH_MAX_QUERIES * 8;
+constexpr size_t SCRATCH_OFF_CNT = SCRATCH_OFF_OFF + (SCRATCH_MAX_QUERIES + 32) * 8;
+constexpr size_t SCRATCH_OFF_ARENA = SCRATCH_OFF_CNT + SCRATCH_MAX_QUERIES * 4;
+constexpr size_t SCRATCH_BYTES = SCRATCH_OFF_ARENA + SCRATCH_ARENA_IDS * 4;       // 29.03 MiB
+static_assert(SCRATCH_OFF_ARENA % 256 == 0 && SCRATCH_OFF_CNT % 256 == 0 && SCRATCH_OFF_OFF % 256 == 0, "256-byte aligned slices");
+
+constexpr int SCRATCH_MAX_DEVICES = 64;
+void *g_scratch_ptr[SCRATCH_MAX_DEVICES] = {nullptr};
+std::mutex g_scratch_mutex;
+
+}  // namespace
+
+static __device__ __align__(256) unsigned char scratch[SCRATCH_BYTES];
+
+namespace {
+
+// This device's copy of the scratch array (the device must be current); nullptr + *err on failure.
+void *scratch_of(int device, hipError_t *err)
+{
+    *err = hipSuccess;
+    if (device < 0 || device >= SCRATCH_MAX_DEVICES) { *err = hipErrorInvalidDevice; return nullptr; }
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void *ptr = nullptr;
+        *err = hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch));
+        if (*err != hipSuccess) return nullptr;
+        g_scratch_ptr[device] = ptr;
+    }
+    return g_scratch_ptr[device];
+}
 
 struct DevBuf {
     void *p = nullptr;
@@ -120,6 +167,7 @@ struct dpf_index {
     int64_t last_nq = 0;
     int32_t last_k = 0;
     bool last_valid = false;
+    unsigned char *scratch_ptr = nullptr;             // this device's copy of the static scratch array
     // dpf_set_option values (0 / default = the library's own choice)
     int32_t opt_emit_cap = 0, opt_bucket_list_cap = 0, opt_first_permille = 100, opt_seed_cap = 256;
     bool opt_sync_sizes = false, opt_short_rerank = true;
@@ -200,6 +248,7 @@ extern "C" int dpf_create(const dpf_config *cfg, dpf_index **out)
     e = hipSetDevice(cfg->device);
     if (e == hipSuccess && configure_kernels() != 0) e = hipErrorInvalidValue;
     if (e == hipSuccess) { int v = 0; e = hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, cfg->device); if (v > 0) ix->num_cus = v; }
+    if (e == hipSuccess) ix->scratch_ptr = (unsigned char *)scratch_of(cfg->device, &e);
     if (e == hipSuccess) e = hipMalloc((void **)&ix->d_short_hash, sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(ix->d_short_hash, 0, sizeof(unsigned long long));
     if (e == hipSuccess) e = hipHostMalloc((void **)&ix->pinned, 8 * sizeof(int64_t), hipHostMallocDefault);
@@ -1132,6 +1181,52 @@ extern "C" int dpf_query_topk_device(dpf_index *ix, const int32_t *d_qids, const
     if (ix->profiling) HIPCHECK(ix, hipEventRecord(ix->ev[5], stream));
     HIPCHECK(ix, hipGetLastError());
     ix->last_path = 0;
+    return DPF_OK;
+}
+
+extern "C" int dpf_query_topk_device_static(dpf_index *ix, const int32_t *d_qids, const void *d_Q, int64_t nq,
+                                            int32_t steps, int32_t k, int32_t *d_ids, double *d_scores, void *stream_)
+{
+    if (!ix) return DPF_EINVAL;
+    int rc = check_ready(ix, true);
+    if (rc != DPF_OK) return rc;
+    if (nq < 0 || steps < 0 || k < 1 || k > 64 || (nq > 0 && (!d_Q || !d_ids || !d_scores)))
+        return fail(ix, DPF_EINVAL, "dpf_query_topk_device_static: bad arguments");
+    if (nq == 0) return DPF_OK;
+    const int64_t row_bytes = ix->dpad * (int64_t)ix->elem;
+    if ((size_t)nq > SCRATCH_MAX_QUERIES || (size_t)(nq * row_bytes) > SCRATCH_QPAD_BYTES ||
+        (size_t)(nq * ix->cfg.num_tables) > SCRATCH_HASH_WORDS)
+        return fail(ix, DPF_ECAPACITY, "dpf_query_topk_device_static: at most " + std::to_string(SCRATCH_MAX_QUERIES) + " queries, " +
+                                       std::to_string(SCRATCH_QPAD_BYTES) + " bytes of padded query rows and " +
+                                       std::to_string(SCRATCH_HASH_WORDS) + " (query, table) pairs per call");
+    if (!ix->scratch_ptr) return fail(ix, DPF_EHIP, "dpf_query_topk_device_static: the scratch array was not located on this device");
+    hipStream_t stream = (hipStream_t)stream_;
+    HIPCHECK(ix, hipSetDevice(ix->cfg.device));
+    unsigned char *const sp = ix->scratch_ptr;
+    ProbeWs w;
+    w.hashes = (int32_t *)(sp + SCRATCH_OFF_HASHES); w.parts = (int32_t *)(sp + SCRATCH_OFF_PARTS);
+    w.raw = (unsigned long long *)(sp + SCRATCH_OFF_RAW); w.bound = (int64_t *)(sp + SCRATCH_OFF_BOUND);
+    w.off = (int64_t *)(sp + SCRATCH_OFF_OFF); w.cnt = (int32_t *)(sp + SCRATCH_OFF_CNT);
+    w.arena = (int32_t *)(sp + SCRATCH_OFF_ARENA); w.arena_ids = (int64_t)SCRATCH_ARENA_IDS;
+    // the rerank kernel reads whole 16-byte pieces: padded copies of the query rows when the rows are no multiple
+    const void *qpad = d_Q;
+    int64_t qstride = ix->cfg.dim;
+    if (ix->dpad != ix->cfg.dim) {
+        launch_copy_rows(ix->cfg.dtype, d_Q, nq, ix->cfg.dim, sp + SCRATCH_OFF_QPAD, ix->dpad, stream);
+        qpad = sp + SCRATCH_OFF_QPAD;
+        qstride = ix->dpad;
+    }
+    // every slice is written in full before it is read (hashes, counts, offsets, set sizes, lists): nothing of
+    // an earlier call's contents is relied on, so nothing needs clearing
+    const bool prof = ix->profiling;
+    ix->profiling = false;
+    rc = run_probe(ix, d_qids, qpad, qstride, nq, steps, stream, &w);
+    ix->profiling = prof;
+    if (rc != DPF_OK) return rc;
+    RerankParams rp;
+    fill_rerank_params(ix, rp, qpad, k, w.off, w.cnt, w.arena, d_ids, d_scores);
+    launch_rerank(ix->cfg.dtype, ix->cfg.metric, rp, nq, stream);
+    HIPCHECK(ix, hipGetLastError());
     return DPF_OK;
 }
 
