@@ -109,6 +109,18 @@ typedef struct dpf_stats {
     int64_t last_sizes_carried;  /* last bucket-major batch: 0 = the host read the batch's list sizes before
                                     filling the lists, 1 = it did not wait for them (buffers sized by earlier
                                     batches), 2 = as 1, but the batch outgrew the buffers and was run again */
+    /* since dpf_create, over the top-k batches of this handle (no device synchronisation needed to read them) */
+    int64_t total_topk_batches;      /* dpf_query_topk / dpf_query_topk_device calls with at least one query   */
+    int64_t total_sized_on_host;     /* bucket-major batches of kind last_sizes_carried = 0                     */
+    int64_t total_carried;           /* ... = 1                                                                 */
+    int64_t total_rerun;             /* ... = 2                                                                 */
+    int64_t total_overflowed;        /* queries answered by the gather path because their forward list overflowed */
+    int64_t total_gather_batches;    /* batches answered by the gather path as a whole                          */
+    /* the bucket-major scan's view of the fitted index (0 when the handle reranks by gather only) */
+    int64_t base16_bytes;            /* HBM bytes of the fp16 copy of the resident rows                          */
+    int64_t tile_rows;               /* rows per scan tile (64, or 16 for rows of more than 768 dimensions)      */
+    int64_t num_tiles;               /* tiles the buckets are cut into                                           */
+    int64_t resident_ids;            /* bucket entries (id, table) of this handle's row / table shard            */
 } dpf_stats;
 
 typedef struct dpf_index dpf_index;

@@ -36,7 +36,10 @@ class DpfStats(C.Structure):
                                   "last_ms_scan")] + [
         (n, C.c_int64) for n in ("last_path", "last_pairs", "last_forwarded", "last_scan_launches", "snapshot_bytes",
                                  "base_bytes")] + [
-        (n, C.c_double) for n in ("fit_ms_hash", "fit_ms_forest", "fit_ms_total")] + [("last_overflowed", C.c_int64), ("last_sizes_carried", C.c_int64)]
+        (n, C.c_double) for n in ("fit_ms_hash", "fit_ms_forest", "fit_ms_total")] + [
+        (n, C.c_int64) for n in ("last_overflowed", "last_sizes_carried", "total_topk_batches", "total_sized_on_host",
+                                 "total_carried", "total_rerun", "total_overflowed", "total_gather_batches",
+                                 "base16_bytes", "tile_rows", "num_tiles", "resident_ids")]
 
 
 EXPORTS = (

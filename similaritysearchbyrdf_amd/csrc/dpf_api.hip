@@ -1168,11 +1168,18 @@ extern "C" int dpf_query_topk_device(dpf_index *ix, const int32_t *d_qids, const
     if ((rc = pad_queries(ix, d_Q, nq, stream, &qpad, &qstride)) != DPF_OK) return rc;
     ix->last_k = k;
     ix->last_timed = ix->profiling;
+    ix->st.total_topk_batches++;
     if (ix->bucket_major && ix->ntiles > 0) {
         bool done = false;
         if ((rc = run_topk_bucket_major(ix, d_qids, qpad, qstride, nq, steps, k, d_ids, d_scores, stream, &done)) != DPF_OK) return rc;
-        if (done) return DPF_OK;
+        if (done) {
+            const int64_t kind = ix->st.last_sizes_carried;
+            (kind == 0 ? ix->st.total_sized_on_host : kind == 1 ? ix->st.total_carried : ix->st.total_rerun)++;
+            ix->st.total_overflowed += ix->st.last_overflowed;
+            return DPF_OK;
+        }
     }
+    ix->st.total_gather_batches++;
     if ((rc = run_probe(ix, d_qids, qpad, qstride, nq, steps, stream)) != DPF_OK) return rc;
     RerankParams rp;
     fill_rerank_params(ix, rp, qpad, k, ix->ws_off.as<int64_t>(), ix->ws_cnt.as<int32_t>(), ix->ws_arena.as<int32_t>(), d_ids, d_scores);
@@ -1469,6 +1476,11 @@ extern "C" int dpf_get_stats(dpf_index *ix, dpf_stats *out)
         if (ix->last_k > 0 && hipEventElapsedTime(&ms, ix->ev[4], ix->ev[5]) == hipSuccess) ix->st.last_ms_rerank = ms;
         (void)hipGetLastError();      // an unrecorded event is not an error of this call
     }
+    ix->st.base16_bytes = ix->bucket_major && ix->ks16 > 0 ? ix->base_rows * (int64_t)ix->ks16 * 64 : 0;
+    ix->st.tile_rows = ix->bucket_major && ix->ks16 > 0 ? leafscan_tile_rows(ix->ks16) : 0;
+    ix->st.num_tiles = ix->ntiles;
+    ix->st.resident_ids = 0;
+    for (uint32_t len : ix->h_leaf_len) ix->st.resident_ids += len;
     *out = ix->st;
     return DPF_OK;
 }

@@ -14,10 +14,12 @@ then a merge by score, then id, with repeated ids taken once):
   a query group is the whole set.  Table groups divide the scan (every rank
   reads its tables' rows once, however few queries it serves); query groups
   divide what is paid per query (hashing, seed thresholds, exact rerank).
-* "rows": the forest and the hash family are replicated, base rows are sharded
-  contiguously, rank r owning ids [r*N/G, (r+1)*N/G).  Every rank hashes and
-  probes the whole query batch but scores only the candidates inside its shard.
-  Used for single-table forests, and when the base rows do not fit one GPU.
+* "rows": the forest and the hash family are replicated; the G ranks form a
+  grid of QG query groups x RG row groups, rank r = (r // RG, r % RG) holds the
+  base rows [j*N/RG, (j+1)*N/RG) of its row group j and answers the queries of
+  its query group: it hashes and probes them over all tables but scores only
+  the candidates inside its row shard.  Used for single-table forests, when the
+  base rows do not fit one GPU, and on request (mode="rows").
 
 The reference is a single JVM process (its "distribution" is the in-process
 sub-index partitioning of Partitioner.scala:27-64), so there is no reference
@@ -45,6 +47,14 @@ def grid_of(world, num_tables):
         if world % d == 0 and d * d <= 4 * world and d <= num_tables:
             tg = d
     return world // tg, tg
+
+
+def rows_grid_of(world):
+    """(query groups, row groups) for `world` ranks in "rows" mode: as many row groups as ranks.  Row
+    groups divide the rows a rank's scan reads; query groups divide the per-query work but leave every
+    rank reading all the rows its queries' buckets hold.  (Measured on one MI355X, c3 shape, per-rank batch
+    time: see tools/shard_timing.py.)"""
+    return 1, world
 
 
 def merge_grid_host(ids, scores, qg, tg, nq, metric):
@@ -137,20 +147,23 @@ class ShardedDpf:
         self.rank, self.world, self.group, self.metric = rank, world, group, metric
         L = num_tables_of(params)
         self.mode = mode or ("tables" if world > 1 and L >= world else "rows")
-        self.qg, self.tg = 1, world
+        if self.mode not in ("tables", "rows"):
+            raise ValueError("mode must be 'tables' or 'rows'")
+        # qg query groups x sg shard groups (table groups or row groups); rank r = (r // sg, r % sg)
+        self.qg, self.sg = grid or (grid_of(world, L) if self.mode == "tables" else rows_grid_of(world))
+        if self.qg * self.sg != world or (self.mode == "tables" and self.sg > L):
+            raise ValueError("grid %r does not cover %d ranks" % ((self.qg, self.sg), world))
         if self.mode == "tables":
-            self.qg, self.tg = grid or grid_of(world, L)
-            if self.qg * self.tg != world:
-                raise ValueError("grid %r does not cover %d ranks" % ((self.qg, self.tg), world))
             self.lo, self.hi = 0, n_total
-            self.t_lo, self.t_hi = table_bounds(L, self.tg, rank % self.tg)
+            self.t_lo, self.t_hi = table_bounds(L, self.sg, rank % self.sg)
             self.index = DpfIndex(params, metric=metric, top_k=top_k, dtype=dtype, device=device,
                                   table_begin=self.t_lo, table_end=self.t_hi)
         else:
-            self.lo, self.hi = shard_bounds(n_total, world, rank)
+            self.lo, self.hi = shard_bounds(n_total, self.sg, rank % self.sg)
             self.t_lo, self.t_hi = 0, L
             self.index = DpfIndex(params, metric=metric, top_k=top_k, dtype=dtype, device=device,
                                   row_begin=self.lo, row_end=self.hi)
+        self.tg = self.sg            # (older name)
         self._bufs = None
 
     def fit(self, X):
@@ -164,11 +177,16 @@ class ShardedDpf:
         per batch (dpf_query_topk_device), the results are complete once `stream` has drained."""
         import torch
         nq = d_Q.shape[0]
+        if d_Q.is_cuda:
+            cur = torch.cuda.current_stream(d_Q.device).cuda_stream
+            if (stream or 0) != cur:
+                raise ValueError("ShardedDpf.query_topk: `stream` must be torch's current stream on the index's device "
+                                 "(the all-gather and the copies are ordered on that one)")
         if self.world == 1:
             self.index.query_topk_device(d_qids.data_ptr(), d_Q.data_ptr(), nq, steps, k, out_ids.data_ptr(),
                                          out_scores.data_ptr(), stream)
             return
-        qg, tg = self.qg, self.tg
+        qg, tg = self.qg, self.sg
         q_lo, q_hi = shard_bounds(nq, qg, self.rank // tg)        # this rank's query group
         m = -(-nq // qg)                                           # rows every rank contributes to the exchange
         if self._bufs is None or self._bufs[0] != (m, k):

@@ -113,3 +113,22 @@ def make_unit_gaussian(n, dim, nq, noise=0.05, seed=777, dtype=np.float32, chunk
     q = X[pick] + (noise / np.sqrt(dim)) * rng.standard_normal((nq, dim), dtype=np.float32)
     Q = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(dtype)
     return X, Q, pick
+
+
+def more_queries(kind, X, nq, seed):
+    """Another query batch over the base X in the recipe of make_clustered ("clustered"), make_sift_like
+    ("sift") or make_unit_gaussian ("unit"), drawn from its own seed.  -> (Q [nq,dim], picked rows)."""
+    rng = np.random.default_rng(seed)
+    n, dim = X.shape
+    pick = rng.integers(0, n, size=nq)
+    g = rng.standard_normal((nq, dim), dtype=np.float32)
+    if kind == "clustered":
+        Q = X[pick].astype(np.float32) + np.float32(0.05) * g
+    elif kind == "sift":
+        Q = np.clip(np.rint(X[pick] + np.float32(4.0) * g), 0, 255)
+    elif kind == "unit":
+        q = X[pick] + np.float32(0.05 / np.sqrt(dim)) * g
+        Q = q / np.linalg.norm(q, axis=1, keepdims=True)
+    else:
+        raise ValueError(kind)
+    return np.ascontiguousarray(Q, dtype=X.dtype), pick

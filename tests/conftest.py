@@ -13,9 +13,11 @@ def pytest_configure(config):
 
 
 def _has_gpu():
+    # device_count() does not initialise the GPU in this process (is_available() would): the multi-rank GPU test
+    # starts its ranks as child processes and has to do so from a parent that has not touched the GPU yet
     try:
         import torch
-        return torch.cuda.is_available()
+        return torch.cuda.device_count() > 0
     except Exception:
         return False
 

@@ -1,37 +1,78 @@
-"""Turns the two counter_collection.csv files of tools/pmc_traffic.sh into the per-launch traffic
-record bench.py reads: python tools/pmc_traffic.py <fetch.csv> <write.csv> <kernel substring>
-<workload> <search steps> <launches per batch> > profiles/rNN_<workload>_<kernel>_pmc_traffic.json"""
+"""Turns the passes of tools/pmc_workload.sh into the per-launch record bench.py reads:
+python tools/pmc_traffic.py <tag> <kernel substring> <workload> <base rows> <queries> <search steps>
+    > profiles/rNN_<workload>_<kernel>_pmc_traffic.json"""
 import csv
+import glob
 import json
 import sys
 from collections import defaultdict
 
+FP16_DENSE_PEAK_TFLOPS = 2500.0      # MI355X dense fp16 matrix peak
+SIMDS = 256 * 4
+CLOCK_GHZ = 2.4
 
-def per_kernel(path, counter):
+
+def find(tag, sub, name):
+    hits = glob.glob("gpurun_out/pmc_%s/%s/**/%s" % (tag, sub, name), recursive=True)
+    if not hits:
+        raise SystemExit("no %s under gpurun_out/pmc_%s/%s" % (name, tag, sub))
+    return hits[0]
+
+
+def per_kernel(path):
     tot, cnt = defaultdict(float), defaultdict(int)
     with open(path) as f:
         for r in csv.DictReader(f):
-            if r["Counter_Name"] != counter:
-                continue
-            name = r["Kernel_Name"].split("(")[0]
-            tot[name] += float(r["Counter_Value"])
-            cnt[name] += 1
-    return {n: {"launches": cnt[n], "avg_kb": tot[n] / cnt[n]} for n in tot}
+            key = (r["Kernel_Name"].split("(")[0], r["Counter_Name"])
+            tot[key] += float(r["Counter_Value"])
+            cnt[key] += 1
+    return {k: (tot[k] / cnt[k], cnt[k]) for k in tot}
 
 
-fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
-key, workload, steps, launches = sys.argv[3], sys.argv[4], int(sys.argv[5]), int(sys.argv[6])
-name = [n for n in fetch if key in n][0]
-f_raw = fetch[name]["avg_kb"] * 1024.0
-w = write[name]["avg_kb"] * 1024.0
-print(json.dumps({
-    "workload": workload,
-    "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 --warmup 1 "
-               "--no-cpu-baseline --no-recall (tools/pmc_traffic.sh)",
-    "kernel": name, "launches_per_batch": launches, "search_steps": steps,
+def kernel_stats(path):
+    out = {}
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            out[r["Name"].split("(")[0]] = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]),
+                                            "total_ns": float(r["TotalDurationNs"]), "percent": float(r["Percentage"])}
+    return out
+
+
+tag, key, workload, n, nq, steps = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])
+fetch = per_kernel(find(tag, "fetch", "p_counter_collection.csv"))
+write = per_kernel(find(tag, "write", "p_counter_collection.csv"))
+mfma = per_kernel(find(tag, "mfma", "p_counter_collection.csv"))
+stats = kernel_stats(find(tag, "kt", "kt_kernel_stats.csv"))
+name = [k[0] for k in fetch if key in k[0]][0]
+f_raw = fetch[(name, "FETCH_SIZE")][0] * 1024.0
+w = write[(name, "WRITE_SIZE")][0] * 1024.0
+avg_ns = stats[name]["avg_ns"]
+rec = {
+    "workload": workload, "base_rows": n, "queries": nq, "search_steps": steps,
+    "command": "tools/pmc_workload.sh %s ...: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE | matrix-core counters (separate passes) and "
+               "--kernel-trace --stats -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-recall "
+               "--no-host-to-host --large-table-rows 0 <workload arguments>" % tag,
+    "kernel": name, "launches_profiled": fetch[(name, "FETCH_SIZE")][1],
+    "avg_duration_us_kernel_trace": avg_ns / 1e3,
     "fetch_size_bytes_raw_per_launch": f_raw, "write_size_bytes_per_launch": w,
-    "correction": "gfx950 FETCH_SIZE tallies 128-B requests at 64 B: read bytes = 2 x FETCH_SIZE. Calibrated on this "
-                  "kernel's own access shape (tools/pmc_calibrate.sh: 4.29 GB of 256-B rows pulled as MFMA operands "
-                  "report FETCH_SIZE 2.1 GB and 34.1 M requests of 128 B).",
+    "correction": "gfx950 FETCH_SIZE tallies 128-B requests at 64 B: read bytes = 2 x FETCH_SIZE (calibrated on this kernel's "
+                  "own access shape, tools/pmc_calibrate.sh); both counters sit at the L2 <-> fabric boundary, so reads "
+                  "served by the Infinity Cache are included",
     "traffic_bytes_per_launch": 2.0 * f_raw + w,
-    "per_kernel": {"FETCH_SIZE": fetch, "WRITE_SIZE": write}}, indent=1))
+}
+mops = mfma.get((name, "SQ_INSTS_VALU_MFMA_MOPS_F16"))
+if mops:
+    flops = mops[0] * 512.0
+    busy = mfma.get((name, "SQ_VALU_MFMA_BUSY_CYCLES"), (0.0, 0))[0]
+    rec.update({
+        "mfma_flops_per_launch": flops,
+        "mfma_instructions_per_launch": mfma.get((name, "SQ_INSTS_MFMA"), (0.0, 0))[0],
+        "mfma_busy_cycles_per_launch": busy,
+        "mfma_tflops": flops / avg_ns / 1e3,
+        "mfma_util": flops / avg_ns / 1e3 / FP16_DENSE_PEAK_TFLOPS,
+        "mfma_busy_share_of_simd_cycles": busy / (avg_ns * CLOCK_GHZ * SIMDS),
+        "mfma_util_definition": "SQ_INSTS_VALU_MFMA_MOPS_F16 x 512 flop / kernel-trace duration / 2500 TFLOP/s (dense fp16 peak); "
+                                "busy share = SQ_VALU_MFMA_BUSY_CYCLES / (duration x 2.4 GHz x 1024 SIMDs)",
+    })
+rec["kernel_stats"] = {k: v for k, v in sorted(stats.items(), key=lambda kv: -kv[1]["total_ns"])[:24]}
+print(json.dumps(rec, indent=1))
