@@ -121,6 +121,8 @@ typedef struct dpf_stats {
     int64_t tile_rows;               /* rows per scan tile (64, or 16 for rows of more than 768 dimensions)      */
     int64_t num_tiles;               /* tiles the buckets are cut into                                           */
     int64_t resident_ids;            /* bucket entries (id, table) of this handle's row / table shard            */
+    int64_t hash_undecided_rows;     /* since dpf_create: vectors whose matrix-core projection fell inside the guard band
+                                        of some function and were hashed again by the exact kernel                       */
 } dpf_stats;
 
 typedef struct dpf_index dpf_index;
@@ -261,7 +263,11 @@ enum {
     DPF_OPT_SYNC_SIZES = 3,          /* 1: the host reads every batch's list sizes before filling the lists */
     DPF_OPT_FIRST_PASS_PERMILLE = 4, /* share of the scan's work units run before the thresholds are refined (100) */
     DPF_OPT_SEED_SAMPLE = 5,         /* candidates per query scored exactly for the first thresholds (256; 16..4096) */
-    DPF_OPT_SHORT_RERANK = 6         /* 0: short candidate lists use the general rerank kernel too (default 1) */
+    DPF_OPT_SHORT_RERANK = 6,        /* 0: short candidate lists use the general rerank kernel too (default 1) */
+    DPF_OPT_PROJECTION_MIN_ROWS = 7  /* batches of at least this many vectors, with dim x num_functions >= 40000, are hashed
+                                        through the matrix-core projection (fp64 MFMA contraction + exact re-evaluation of
+                                        undecided rows; same hashes bit for bit); others by the exact vector-ALU kernel alone.
+                                        Default 4096; 0 = never; 1 = always, whatever the shape */
 };
 int dpf_set_option(dpf_index *ix, int32_t option, int64_t value);
 

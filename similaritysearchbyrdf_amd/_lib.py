@@ -39,7 +39,7 @@ class DpfStats(C.Structure):
         (n, C.c_double) for n in ("fit_ms_hash", "fit_ms_forest", "fit_ms_total")] + [
         (n, C.c_int64) for n in ("last_overflowed", "last_sizes_carried", "total_topk_batches", "total_sized_on_host",
                                  "total_carried", "total_rerun", "total_overflowed", "total_gather_batches",
-                                 "base16_bytes", "tile_rows", "num_tiles", "resident_ids")]
+                                 "base16_bytes", "tile_rows", "num_tiles", "resident_ids", "hash_undecided_rows")]
 
 
 EXPORTS = (
@@ -52,7 +52,7 @@ EXPORTS = (
 
 # dpf_set_option keys (include/dpf.h)
 OPTION = {"emit_cap": 1, "bucket_list_cap": 2, "sync_sizes": 3, "first_pass_permille": 4, "seed_sample": 5,
-          "short_rerank": 6}
+          "short_rerank": 6, "projection_min_rows": 7}
 
 _lib = None
 

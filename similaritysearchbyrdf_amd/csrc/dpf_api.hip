@@ -117,7 +117,9 @@ struct dpf_index {
 
     std::vector<double> fns, b, part_fns, part_b;
     std::vector<int32_t> w, chain_fn, part_w;
-    DevBuf d_fnsT, d_b, d_w, d_chain, d_part_fns, d_part_b, d_part_w;
+    DevBuf d_fnsT, d_b, d_w, d_chain, d_part_fns, d_part_b, d_part_w, d_fn_norm;
+    DevBuf ws_proj_codes, ws_proj_norm, ws_proj_flag, ws_proj_rows;   // matrix-core projection (dpf_project.hip)
+    unsigned char *d_proj_counters = nullptr;                         // [0] undecided rows of the last call (u32), [8] running total (u64)
     HashParams hp{};
 
     int64_t n = 0;
@@ -171,6 +173,7 @@ struct dpf_index {
     // dpf_set_option values (0 / default = the library's own choice)
     int32_t opt_emit_cap = 0, opt_bucket_list_cap = 0, opt_first_permille = 100, opt_seed_cap = 256;
     bool opt_sync_sizes = false, opt_short_rerank = true;
+    int64_t opt_projection_min_rows = 4096;           // batches of at least this many vectors hash on the matrix cores (0: never)
 };
 
 #define HIPCHECK(ix, call)                                                              \
@@ -251,6 +254,8 @@ extern "C" int dpf_create(const dpf_config *cfg, dpf_index **out)
     if (e == hipSuccess) ix->scratch_ptr = (unsigned char *)scratch_of(cfg->device, &e);
     if (e == hipSuccess) e = hipMalloc((void **)&ix->d_short_hash, sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(ix->d_short_hash, 0, sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void **)&ix->d_proj_counters, 16);
+    if (e == hipSuccess) e = hipMemset(ix->d_proj_counters, 0, 16);
     if (e == hipSuccess) e = hipHostMalloc((void **)&ix->pinned, 8 * sizeof(int64_t), hipHostMallocDefault);
     for (int i = 0; i < 6 && e == hipSuccess; i++) e = hipEventCreate(&ix->ev[i]);
     for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipEventCreate(&ix->ev_scan[i]);
@@ -289,6 +294,8 @@ extern "C" void dpf_destroy(dpf_index *ix)
                       &ix->d_hashes, &ix->d_parts};
     for (DevBuf *b : bufs) b->release();
     if (ix->d_short_hash) (void)hipFree(ix->d_short_hash);
+    if (ix->d_proj_counters) (void)hipFree(ix->d_proj_counters);
+    { DevBuf *pb[] = {&ix->d_fn_norm, &ix->ws_proj_codes, &ix->ws_proj_norm, &ix->ws_proj_flag, &ix->ws_proj_rows}; for (DevBuf *b : pb) b->release(); }
     if (ix->pinned) (void)hipHostFree(ix->pinned);
     for (int i = 0; i < 6; i++) if (ix->ev[i]) (void)hipEventDestroy(ix->ev[i]);
     for (int i = 0; i < 4; i++) if (ix->ev_scan[i]) (void)hipEventDestroy(ix->ev_scan[i]);
@@ -338,6 +345,16 @@ extern "C" int dpf_set_hash_family(dpf_index *ix, const double *fns, const doubl
         if ((rc = upload(ix, ix->d_b, ix->b)) != DPF_OK) return rc;
         if ((rc = upload(ix, ix->d_w, ix->w)) != DPF_OK) return rc;
     }
+    {   // Euclidean norm of every pool function: the matrix-core projection's guard band is proportional to it
+        std::vector<double> nrm(F);
+        for (size_t f = 0; f < F; f++) {
+            double s = 0.0;
+            for (size_t i = 0; i < d; i++) s += fns[f * d + i] * fns[f * d + i];
+            nrm[f] = std::sqrt(s);
+        }
+        if ((rc = upload(ix, ix->d_fn_norm, nrm)) != DPF_OK) return rc;
+    }
+    ix->hp.fn_norm = ix->d_fn_norm.as<double>();
     ix->hp.fnsT = ix->d_fnsT.as<double>();
     ix->hp.chain_fn = ix->d_chain.as<int32_t>();
     ix->hp.b = ix->d_b.as<double>();
@@ -393,6 +410,36 @@ static int check_ready(dpf_index *ix, bool need_fit)
     if (ix->cfg.partition_bits > 0 && !ix->have_part) return fail(ix, DPF_ENOFAMILY, "partitioner not set (dpf_set_partitioner)");
     if (need_fit && (ix->cfg.flags & DPF_FLAG_HASH_ONLY)) return fail(ix, DPF_EINVAL, "this handle was created hash-only");
     if (need_fit && !ix->fitted) return fail(ix, DPF_ENOTFIT, "need to fit the data first");
+    return DPF_OK;
+}
+
+// Hashes and sub-index ids of n vectors (device rows, `stride` elements apart): large batches go through the
+// matrix-core projection (same results bit for bit), small ones and callers that may not allocate through the
+// exact vector-ALU kernel alone.
+static int hash_rows(dpf_index *ix, const void *X, int64_t stride, int64_t n, int32_t *hashes, int32_t *parts, hipStream_t stream,
+                     bool may_alloc = true)
+{
+    if (n <= 0) return DPF_OK;
+    // the contraction pays from a few thousand vectors on and when a vector meets enough work (dim x functions);
+    // below that the exact kernel alone is as fast and takes one launch instead of four
+    const bool forced = ix->opt_projection_min_rows == 1;
+    const bool worth = n >= ix->opt_projection_min_rows && (int64_t)ix->cfg.dim * ix->cfg.num_functions >= 40000;
+    if (!may_alloc || ix->opt_projection_min_rows <= 0 || !(forced || worth)) {
+        launch_hash(ix->cfg.dtype, X, stride, n, ix->hp, hashes, parts, stream);
+        return DPF_OK;
+    }
+    HIPCHECK(ix, ix->ws_proj_codes.ensure(std::max<size_t>(project_codes_bytes(ix->hp, n), 16)));
+    HIPCHECK(ix, ix->ws_proj_norm.ensure((size_t)n * 8));
+    HIPCHECK(ix, ix->ws_proj_flag.ensure((size_t)n * 4));
+    HIPCHECK(ix, ix->ws_proj_rows.ensure((size_t)n * 4));
+    ProjectWs ws;
+    ws.codes = ix->ws_proj_codes.p;
+    ws.row_norm = ix->ws_proj_norm.as<double>();
+    ws.row_flag = ix->ws_proj_flag.as<uint32_t>();
+    ws.flag_rows = ix->ws_proj_rows.as<int32_t>();
+    ws.flag_count = (uint32_t *)ix->d_proj_counters;
+    ws.flag_total = (unsigned long long *)(ix->d_proj_counters + 8);
+    launch_hash_mfma(ix->cfg.dtype, X, stride, n, ix->hp, ws, hashes, parts, stream);
     return DPF_OK;
 }
 
@@ -594,8 +641,8 @@ extern "C" int dpf_fit(dpf_index *ix, const void *X, int64_t n)
         const char *src = (const char *)X + (size_t)s * d * ix->elem;
         HIPCHECK(ix, hipMemcpy(ix->ws_stage.p, src, (size_t)cnt * d * ix->elem, hipMemcpyHostToDevice));
         const int64_t g0 = first + s, g1 = g0 + cnt;
-        launch_hash(c.dtype, ix->ws_stage.p, d, cnt, ix->hp, ix->d_hashes.as<int32_t>() + (size_t)g0 * L,
-                    ix->d_parts.as<int32_t>() + (size_t)g0 * L, nullptr);
+        if ((rc = hash_rows(ix, ix->ws_stage.p, d, cnt, ix->d_hashes.as<int32_t>() + (size_t)g0 * L,
+                            ix->d_parts.as<int32_t>() + (size_t)g0 * L, nullptr)) != DPF_OK) return rc;
         // rows of this batch that belong to the resident shard
         const int64_t a = std::max(g0, res_begin), bnd = std::min(g1, res_end);
         if (bnd > a) {
@@ -874,7 +921,10 @@ static int run_probe(dpf_index *ix, const int32_t *d_qids, const void *d_Qpad, i
     }
     ProbeWs w = fixed ? *fixed : handle_ws(ix);
     if (ix->profiling) HIPCHECK(ix, hipEventRecord(ix->ev[0], stream));
-    launch_hash(ix->cfg.dtype, d_Qpad, q_stride, nq, ix->hp, w.hashes, w.parts, stream);
+    {
+        const int hrc = hash_rows(ix, d_Qpad, q_stride, nq, w.hashes, w.parts, stream, fixed == nullptr);
+        if (hrc != DPF_OK) return hrc;
+    }
     if (ix->profiling) HIPCHECK(ix, hipEventRecord(ix->ev[1], stream));
     ProbeParams pp;
     fill_probe_params(ix, pp, d_qids, steps, w);
@@ -960,7 +1010,10 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     HIPCHECK(ix, ix->ws_tau.ensure((size_t)nq * 4));
 
     if (ix->profiling) HIPCHECK(ix, hipEventRecord(ix->ev[0], stream));
-    launch_hash(ix->cfg.dtype, qpad, qstride, nq, ix->hp, ix->ws_hashes.as<int32_t>(), ix->ws_parts.as<int32_t>(), stream);
+    {
+        const int hrc = hash_rows(ix, qpad, qstride, nq, ix->ws_hashes.as<int32_t>(), ix->ws_parts.as<int32_t>(), stream);
+        if (hrc != DPF_OK) return hrc;
+    }
     if (ix->profiling) HIPCHECK(ix, hipEventRecord(ix->ev[1], stream));
     HIPCHECK(ix, hipMemsetAsync(ix->ws_lq_cnt.p, 0, lq_cnt_bytes, stream));
     HIPCHECK(ix, hipMemsetAsync(ix->ws_flag.p, 0, flag_bytes, stream));
@@ -1278,7 +1331,7 @@ extern "C" int dpf_hash_batch(dpf_index *ix, const void *Q, int64_t nq, int32_t 
     HIPCHECK(ix, ix->ws_hashes.ensure((size_t)nq * L * 4));
     HIPCHECK(ix, ix->ws_parts.ensure((size_t)nq * L * 4));
     HIPCHECK(ix, hipMemcpy(ix->ws_hq.p, Q, qbytes, hipMemcpyHostToDevice));
-    launch_hash(ix->cfg.dtype, ix->ws_hq.p, ix->cfg.dim, nq, ix->hp, ix->ws_hashes.as<int32_t>(), ix->ws_parts.as<int32_t>(), nullptr);
+    if ((rc = hash_rows(ix, ix->ws_hq.p, ix->cfg.dim, nq, ix->ws_hashes.as<int32_t>(), ix->ws_parts.as<int32_t>(), nullptr)) != DPF_OK) return rc;
     HIPCHECK(ix, hipGetLastError());
     HIPCHECK(ix, hipMemcpy(hashes, ix->ws_hashes.p, (size_t)nq * L * 4, hipMemcpyDeviceToHost));
     if (parts) HIPCHECK(ix, hipMemcpy(parts, ix->ws_parts.p, (size_t)nq * L * 4, hipMemcpyDeviceToHost));
@@ -1419,6 +1472,10 @@ extern "C" int dpf_set_option(dpf_index *ix, int32_t option, int64_t value)
     case DPF_OPT_SHORT_RERANK:
         ix->opt_short_rerank = value != 0;
         return DPF_OK;
+    case DPF_OPT_PROJECTION_MIN_ROWS:
+        if (value < 0) return fail(ix, DPF_EINVAL, "dpf_set_option: the row count must not be negative");
+        ix->opt_projection_min_rows = value;
+        return DPF_OK;
     default:
         return fail(ix, DPF_EINVAL, "dpf_set_option: unknown option");
     }
@@ -1453,6 +1510,11 @@ extern "C" int dpf_get_stats(dpf_index *ix, dpf_stats *out)
     unsigned long long sh = 0;
     HIPCHECK(ix, hipMemcpy(&sh, ix->d_short_hash, 8, hipMemcpyDeviceToHost));
     ix->st.short_hash_events = (int64_t)sh;
+    {
+        unsigned long long und = 0;
+        HIPCHECK(ix, hipMemcpy(&und, ix->d_proj_counters + 8, 8, hipMemcpyDeviceToHost));
+        ix->st.hash_undecided_rows = (int64_t)und;
+    }
     int rc = last_totals(ix, &ix->st.last_raw_candidates, &ix->st.last_unique_candidates);
     if (rc != DPF_OK) return rc;
     ix->st.last_path = ix->last_valid ? ix->last_path : 0;

@@ -22,6 +22,7 @@ struct HashParams {
     const double *part_fns;  // [L][pb][32]
     const double *part_b;    // [L][pb]
     const int32_t *part_w;   // [L][pb]
+    const double *fn_norm;   // [F]       Euclidean norms of the pool functions (matrix-core projection)
     int32_t sampling_index[32];
     int32_t angle_label_lut[29];
 };
@@ -116,7 +117,23 @@ struct RerankParams {
 
 void launch_hash(int dtype, const void *X, int64_t x_stride, int64_t n, const HashParams &p,
                  int32_t *hashes, int32_t *parts, hipStream_t stream);
+// the same kernel over the rows row_list[0 .. *row_count) (device memory), n = capacity of the list
+void launch_hash_rows(int dtype, const void *X, int64_t x_stride, int64_t n, const HashParams &p, int32_t *hashes, int32_t *parts,
+                      const int32_t *row_list, const uint32_t *row_count, hipStream_t stream);
 size_t hash_shmem_bytes(const HashParams &p);
+
+// Matrix-core projection (dpf_project.hip): the same hashes and sub-index ids as launch_hash, bit for bit.
+struct ProjectWs {
+    void *codes = nullptr;           // angle: uint16 [n][ceil(F/16)] sign bits; pStable: int32 [n][F] bucket indices
+    double *row_norm = nullptr;      // [n]
+    uint32_t *row_flag = nullptr;    // [n] 1 = undecided, hashed by the exact kernel afterwards
+    int32_t *flag_rows = nullptr;    // [n] the undecided rows
+    uint32_t *flag_count = nullptr;  // [0] undecided rows of this call
+    unsigned long long *flag_total = nullptr;   // running total over all calls (statistics)
+};
+size_t project_codes_bytes(const HashParams &p, int64_t n);
+void launch_hash_mfma(int dtype, const void *X, int64_t x_stride, int64_t n, const HashParams &p, const ProjectWs &ws,
+                      int32_t *hashes, int32_t *parts, hipStream_t stream);
 void launch_probe(int mode, const ProbeParams &p, int64_t nq, hipStream_t stream);
 void launch_fill_lists(const ProbeParams &p, int64_t nq, hipStream_t stream);
 void launch_leafscan(int metric, const LeafScanParams &p, hipStream_t stream);

@@ -26,6 +26,7 @@
 #include <cstring>
 
 #include "dpf_device.hpp"
+#include "dpf_hash_common.hpp"
 
 #pragma clang fp contract(off)
 
@@ -34,80 +35,6 @@
 #endif
 
 namespace dpf {
-
-// ---------------------------------------------------------------------------
-// hash post-transforms (LSH.scala:152-162)
-// ---------------------------------------------------------------------------
-
-// significantBits.continueBitsCount(key, Array(6,4,2,1)) -- significantBits.scala:11-67
-__device__ inline int32_t continue_bits_count(int32_t key)
-{
-    const uint32_t k = (uint32_t)key;
-    int a0 = 0, a1 = 0, a2 = 0, a3 = 0, count = 0;
-    for (int i = 0; i < 28; i++) {
-        bool one = (k >> i) & 1u;
-        if (one) count++;
-        if (!one || i == 27) {
-            if (count >= 6) { a0++; a1++; a2++; a3++; }
-            else if (count >= 4) { a1++; a2++; a3++; }
-            else if (count >= 2) { a2++; a3++; }
-            else if (count >= 1) { a3++; }
-            count = 0;
-        }
-    }
-    uint32_t tmp = ((uint32_t)a3 << 21) + ((uint32_t)a2 << 14) + ((uint32_t)a1 << 7) + (uint32_t)a0;
-    tmp += (k >> 28) << 28;
-    return (int32_t)tmp;
-}
-
-// Sampling.samplingOneKey -- Sampling.scala:32-39
-__device__ inline int32_t sampling_one_key(int32_t key, const int32_t *si)
-{
-    uint32_t tmp = 0;
-    for (int j = 0; j < 32; j++) tmp += (((uint32_t)key >> (si[j] & 31)) & 1u) << (31 - j);
-    return (int32_t)tmp;
-}
-
-// significantBits.newMethod -- significantBits.scala:113-127.  The angle it
-// thresholds depends only on the popcount of the low 28 bits, so the label is a
-// 29-entry table (computed on the host with the same formula).
-__device__ inline int32_t angle_new_method(int32_t key, const int32_t *label_lut)
-{
-    const uint32_t k = (uint32_t)key, mask = 0x7f;
-    uint32_t label = (uint32_t)label_lut[__popc(k & 0x0fffffffu)];
-    return (int32_t)((k & mask) + (((k >> 7) & mask) << 7) + (label << 14) + (((k >> 21) & mask) << 21) +
-                     (((k >> 28) & mask) << 28));
-}
-
-__device__ inline int32_t apply_type_of_index(int32_t h, const HashParams &p)
-{
-    switch (p.type_of_index) {
-    case 1: return sampling_one_key(h, p.sampling_index);
-    case 2: return continue_bits_count(h);
-    case 3: return angle_new_method(h, p.angle_label_lut);
-    default: return h;
-    }
-}
-
-// Scala Double.toInt: NaN -> 0, saturating, toward zero (PStable:130)
-__device__ inline int32_t d2i_sat(double x)
-{
-    if (x != x) return 0;
-    if (x >= 2147483647.0) return 2147483647;
-    if (x <= -2147483648.0) return (int32_t)0x80000000;
-    return (int32_t)x;
-}
-
-// java.util.Arrays.hashCode over the four big-endian bytes of idx (ByteArrayWrapper.scala:11-14)
-__device__ inline uint32_t hash_int_bytes(uint32_t r, int32_t idx)
-{
-#pragma unroll
-    for (int s = 24; s >= 0; s -= 8) {
-        int32_t byte = (int32_t)(int8_t)(((uint32_t)idx >> s) & 0xff);
-        r = 31u * r + (uint32_t)byte;
-    }
-    return r;
-}
 
 // ---------------------------------------------------------------------------
 // k_hash
@@ -121,10 +48,14 @@ __device__ inline uint32_t hash_int_bytes(uint32_t r, int32_t idx)
 // fp64 sum of Sim:40-49 -- bit-identical hash bits, no guard band needed.
 // The pool is read through its transpose fnsT[dim][F] (coalesced across fl,
 // L2-resident); the vector tile sits in LDS and is read as a broadcast.
-template <typename T, int QT>
+// With row_list the kernel hashes the rows row_list[0 .. *row_count) instead of rows 0 .. n-1 (the rows the
+// matrix-core projection could not decide, see dpf_project.hip); the grid covers the worst case and blocks past
+// the count leave at once.
+template <typename T, int QT, bool LIST>
 __global__ __launch_bounds__(256) void k_hash(const T *__restrict__ X, int64_t x_stride, int64_t n,
                                               HashParams p, int FT,
-                                              int32_t *__restrict__ hashes, int32_t *__restrict__ parts)
+                                              int32_t *__restrict__ hashes, int32_t *__restrict__ parts,
+                                              const int32_t *__restrict__ row_list, const uint32_t *__restrict__ row_count)
 {
     extern __shared__ double sm[];
     const int G = 256 / FT;
@@ -132,12 +63,15 @@ __global__ __launch_bounds__(256) void k_hash(const T *__restrict__ X, int64_t x
     double *xs = sm;                          // [tile][dim]
     double *dots = sm + (size_t)tile * p.dim; // [tile][F]
     const int tid = threadIdx.x;
-    const int64_t q0 = (int64_t)blockIdx.x * tile;
+    if (LIST) n = (int64_t)*row_count < n ? (int64_t)*row_count : n;
+    auto row_of = [&](int64_t at) { return LIST ? (int64_t)row_list[at] : at; };
+    // (a list is worked through by a small grid in strides; the plain form has one tile per workgroup)
+    for (int64_t q0 = (int64_t)blockIdx.x * tile; q0 < n; q0 += (int64_t)gridDim.x * tile) {
+    if (LIST) __syncthreads();
 
     for (int idx = tid; idx < tile * p.dim; idx += 256) {
         int q = idx / p.dim, i = idx - q * p.dim;
-        int64_t row = q0 + q;
-        xs[idx] = row < n ? (double)X[row * x_stride + i] : 0.0;
+        xs[idx] = q0 + q < n ? (double)X[row_of(q0 + q) * x_stride + i] : 0.0;
     }
     __syncthreads();
 
@@ -166,61 +100,23 @@ __global__ __launch_bounds__(256) void k_hash(const T *__restrict__ X, int64_t x
 
     for (int idx = tid; idx < tile * p.L; idx += 256) {
         const int q = idx / p.L, t = idx - q * p.L;
-        const int64_t row = q0 + q;
-        if (row >= n) continue;
+        if (q0 + q >= n) continue;
+        const int64_t row = row_of(q0 + q);
         const double *dq = dots + (size_t)q * p.F;
-        const int32_t *chain = p.chain_fn + (size_t)t * p.m;
-        int32_t h;
-        if (p.family == 0) {
-            // Angle:187-195: result = result << 1 | sign(dot); sign(x) = 0 iff x <= 0 (Angle:184)
-            uint32_t result = 0;
-            for (int j = 0; j < p.m; j++) {
-                const double s = dq[chain[j]];
-                result = (result << 1) | ((s <= 0) ? 0u : 1u);
-            }
-            h = (int32_t)(result << ((32 - p.m) & 31));
-        } else {
-            // PStable:122-143
-            uint32_t r = 1;
-            for (int j = 0; j < p.m; j++) {
-                const int f = chain[j];
-                double v = dq[f] + p.b[f];
-                v = v / (double)p.w[f];
-                r = hash_int_bytes(r, d2i_sat(v));
-            }
-            h = (int32_t)r;
-        }
-        h = apply_type_of_index(h, p);
+        int32_t h, part;
+        assemble_hash(p, t,
+                      [&](int f) { return dq[f] <= 0 ? 0u : 1u; },                                  // Angle:184
+                      [&](int f) { double v = dq[f] + p.b[f]; v = v / (double)p.w[f]; return d2i_sat(v); },   // PStable:130
+                      h, part);
         hashes[row * p.L + t] = h;
-
-        // Part:40-59: set bits of h -> 32-dim 0/1 vector -> the table's own
-        // partitioner chain (ascending-bit fp64 sum, Sim:9-27) -> top pb bits.
-        int32_t part = 0;
-        if (p.pb > 0) {
-            const double *pf = p.part_fns + (size_t)t * p.pb * 32;
-            uint32_t presult = 0, pr = 1;
-            for (int j = 0; j < p.pb; j++) {
-                double s = 0.0;
-                for (int i = 0; i < 32; i++)
-                    if (((uint32_t)h >> i) & 1u) s = s + pf[j * 32 + i];
-                if (p.family == 0) {
-                    presult = (presult << 1) | ((s <= 0) ? 0u : 1u);
-                } else {
-                    double v = s + p.part_b[t * p.pb + j];
-                    v = v / (double)p.part_w[t * p.pb + j];
-                    pr = hash_int_bytes(pr, d2i_sat(v));
-                }
-            }
-            int32_t ph = p.family == 0 ? (int32_t)(presult << ((32 - p.pb) & 31)) : (int32_t)pr;
-            ph = apply_type_of_index(ph, p);
-            part = (int32_t)((uint32_t)ph >> ((32 - p.pb) & 31));
-        }
         if (parts) parts[row * p.L + t] = part;
+    }
+    if (!LIST) break;
     }
 }
 
-void launch_hash(int dtype, const void *X, int64_t x_stride, int64_t n, const HashParams &p,
-                 int32_t *hashes, int32_t *parts, hipStream_t stream)
+void launch_hash_rows(int dtype, const void *X, int64_t x_stride, int64_t n, const HashParams &p, int32_t *hashes, int32_t *parts,
+                      const int32_t *row_list, const uint32_t *row_count, hipStream_t stream)
 {
     if (n <= 0) return;
     int FT = p.F <= 64 ? 64 : (p.F <= 128 ? 128 : 256);
@@ -228,12 +124,19 @@ void launch_hash(int dtype, const void *X, int64_t x_stride, int64_t n, const Ha
     int tile = (256 / FT) * QT;
     size_t shmem = (size_t)tile * (p.dim + p.F) * sizeof(double);
     unsigned grid = (unsigned)((n + tile - 1) / tile);
-    if (dtype == 0)
-        hipLaunchKernelGGL((k_hash<float, QT>), dim3(grid), dim3(256), shmem, stream,
-                           (const float *)X, x_stride, n, p, FT, hashes, parts);
-    else
-        hipLaunchKernelGGL((k_hash<double, QT>), dim3(grid), dim3(256), shmem, stream,
-                           (const double *)X, x_stride, n, p, FT, hashes, parts);
+    if (row_list) grid = std::min(grid, 512u);             // usually (almost) empty: keep the launch cheap
+#define DPF_HASH(T, LIST)                                                                                          \
+    hipLaunchKernelGGL((k_hash<T, QT, LIST>), dim3(grid), dim3(256), shmem, stream, (const T *)X, x_stride, n, p, FT, \
+                       hashes, parts, row_list, row_count)
+    if (dtype == 0) { if (row_list) DPF_HASH(float, true); else DPF_HASH(float, false); }
+    else { if (row_list) DPF_HASH(double, true); else DPF_HASH(double, false); }
+#undef DPF_HASH
+}
+
+void launch_hash(int dtype, const void *X, int64_t x_stride, int64_t n, const HashParams &p,
+                 int32_t *hashes, int32_t *parts, hipStream_t stream)
+{
+    launch_hash_rows(dtype, X, x_stride, n, p, hashes, parts, nullptr, nullptr, stream);
 }
 
 size_t hash_shmem_bytes(const HashParams &p)
@@ -2019,9 +1922,13 @@ int configure_kernels()
 {
     const int max_lds = 160 * 1024;
     hipError_t e;
-    e = hipFuncSetAttribute((const void *)k_hash<float, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    e = hipFuncSetAttribute((const void *)k_hash<float, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute((const void *)k_hash<double, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    e = hipFuncSetAttribute((const void *)k_hash<double, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void *)k_hash<float, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void *)k_hash<double, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute((const void *)k_probe<1>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
     if (e != hipSuccess) return (int)e;

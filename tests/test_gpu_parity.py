@@ -42,6 +42,82 @@ def test_hash_and_partition_bit_exact(family, dtype, toi):
         assert np.array_equal(p[:, t], op)
 
 
+@pytest.mark.parametrize("family,dtype,dim,fsize", [
+    ("angle", np.float32, 100, 100), ("angle", np.float64, 100, 100), ("pStable", np.float32, 100, 100),
+    ("pStable", np.float64, 33, 70), ("angle", np.float32, 3, 40), ("angle", np.float32, 130, 200),
+    ("angle", np.float32, 768, 768), ("pStable", np.float32, 257, 129), ("angle", np.float64, 31, 33),
+])
+def test_matrix_core_projection_equals_exact_kernel_and_oracle(family, dtype, dim, fsize):
+    # the fp64 MFMA contraction with its guard band + exact re-evaluation against the exact vector-ALU kernel
+    # (every row) and the oracle (a sample): hashes and sub-index ids identical
+    kw = dict(table_num=3, permutation_num=2) if family == "angle" else dict(table_num=4, permutation_num=1)
+    params, X, Q, _ = make_problem(n=5000, nq=8, dim=dim, family=family, dtype=dtype, family_size=fsize, **kw)
+    X[7] = 0                                            # an all-zero row: every dot product is exactly 0
+    X[11] = X[10]
+    mfma = DpfIndex(params, dtype=dtype)
+    mfma.set_option("projection_min_rows", 1)
+    exact = DpfIndex(params, dtype=dtype)
+    exact.set_option("projection_min_rows", 0)
+    hm, pm = mfma.hash_batch(X)
+    he, pe = exact.hash_batch(X)
+    assert np.array_equal(hm, he) and np.array_equal(pm, pe)
+    # (the all-zero row is undecided for the angle family: sign(0); a pStable bucket index of b / w is decided)
+    assert mfma.stats()["hash_undecided_rows"] >= (1 if family == "angle" else 0) and exact.stats()["hash_undecided_rows"] == 0
+    orc = O.OracleIndex(params)
+    want = orc.hashes(X[:200].astype(np.float64))
+    assert np.array_equal(hm[:200], want)
+    # odd batch sizes (partial tiles)
+    for n in (1, 15, 129, 1000):
+        h2, p2 = mfma.hash_batch(X[:n])
+        assert np.array_equal(h2, he[:n]) and np.array_equal(p2, pe[:n])
+
+
+@pytest.mark.parametrize("family", ["angle", "pStable"])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_matrix_core_projection_on_decision_boundaries(family, dtype):
+    # vectors built so that one dot product per row sits on a decision boundary up to rounding noise: orthogonal to
+    # a pool function (angle: the sign is decided by the last bits of the left-to-right sum) or landing on an
+    # integer bucket boundary (pStable).  The guard band must catch every such row and the exact kernel decide it.
+    dim = 64
+    params, X, Q, _ = make_problem(n=4000, nq=8, dim=dim, family=family, dtype=np.float64, family_size=96, pstable_w=3,
+                                   **(dict(table_num=3, permutation_num=1)))
+    fns = np.asarray(params["fns"], dtype=np.float64)
+    rng = np.random.default_rng(3)
+    X = X.astype(np.float64)
+    for i in range(X.shape[0]):
+        a = fns[rng.integers(0, fns.shape[0])]
+        if family == "angle":
+            target = 0.0
+        else:
+            f = int(np.flatnonzero((fns == a).all(axis=1))[0])
+            target = float(rng.integers(-3, 4)) * float(params["w"][f]) - float(params["b"][f])
+        X[i] = X[i] + (target - a @ X[i]) / (a @ a) * a
+    X = np.ascontiguousarray(X, dtype=dtype)            # float32 rounding moves the rows off the boundary a little: both kinds occur
+    mfma = DpfIndex(params, dtype=dtype)
+    mfma.set_option("projection_min_rows", 1)
+    hm, pm = mfma.hash_batch(X)
+    orc = O.OracleIndex(params)
+    want = orc.hashes(X.astype(np.float64))
+    assert np.array_equal(hm, want)
+    if dtype == np.float64:
+        assert mfma.stats()["hash_undecided_rows"] > 100     # the boundary rows were recognised as such
+
+
+def test_fit_through_matrix_core_projection_builds_the_same_forest():
+    params, X, Q, pick = make_problem(n=30000, nq=64, bucket_overflow=40, table_num=3, permutation_num=2)
+    a = DpfIndex(params, metric="l2")
+    a.set_option("projection_min_rows", 1)
+    b = DpfIndex(params, metric="l2")
+    b.set_option("projection_min_rows", 0)
+    a.fit(X)
+    b.fit(X)
+    for x, y in zip(a.snapshot(), b.snapshot()):
+        assert np.array_equal(x, y)
+    ai, as_ = a.query_topk(pick, Q, steps=1, k=10)
+    bi, bs = b.query_topk(pick, Q, steps=1, k=10)
+    assert np.array_equal(ai, bi) and np.array_equal(as_, bs, equal_nan=True)
+
+
 def test_hash_exact_zero_dot_products():
     # sign(0) = 0 (AngleHashFamily.scala:184): integer data makes exact zeros likely
     rng = np.random.default_rng(5)
@@ -55,6 +131,10 @@ def test_hash_exact_zero_dot_products():
     h, p = gpu.hash_batch(X)
     want = orc.hashes(X.astype(np.float64))
     assert np.array_equal(h, want)
+    viamfma = DpfIndex(params)
+    viamfma.set_option("projection_min_rows", 1)         # exact zeros through the matrix cores: all undecided, all re-evaluated
+    h2, p2 = viamfma.hash_batch(X)
+    assert np.array_equal(h2, want) and np.array_equal(p2, p)
     assert ((X.astype(np.float64) @ fns.T) == 0).any()
     for i in range(0, 4000, 13):
         assert p[i, 0] == orc.partition(0, want[i, 0])
