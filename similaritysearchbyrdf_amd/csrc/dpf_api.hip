@@ -155,7 +155,7 @@ struct dpf_index {
     DevBuf ws_qpad, ws_hashes, ws_parts, ws_raw, ws_bound, ws_off, ws_cnt, ws_arena, ws_misc;
     DevBuf ws_hq, ws_hqids, ws_hids, ws_hscores;     // device copies for the host-pointer entry points
     DevBuf ws_stage;                                  // fit staging
-    DevBuf ws_lq_cnt, ws_lq_off, ws_lq_cursor, ws_leaf_queries, ws_seed_cand, ws_seed_cnt, ws_seed_ids,
+    DevBuf ws_lq_off, ws_lq_cursor, ws_leaf_queries, ws_seed_cand, ws_seed_cnt, ws_seed_ids,
         ws_seed_scores, ws_emit, ws_emit_cnt, ws_flag, ws_tau;
     hipEvent_t ev_scan[4]{};                          // first and second pass of the scan
     int scan_launches = 0;
@@ -299,7 +299,7 @@ extern "C" void dpf_destroy(dpf_index *ix)
     if (ix->pinned) (void)hipHostFree(ix->pinned);
     for (int i = 0; i < 6; i++) if (ix->ev[i]) (void)hipEventDestroy(ix->ev[i]);
     for (int i = 0; i < 4; i++) if (ix->ev_scan[i]) (void)hipEventDestroy(ix->ev_scan[i]);
-    DevBuf *more[] = {&ix->ws_emit_ucnt, &ix->ws_emit_v, &ix->ws_leaf_units, &ix->ws_unit_off, &ix->ws_q_leaves, &ix->ws_q_leaf_cnt, &ix->d_leaf_tile0, &ix->ws_units, &ix->d_tiles, &ix->ws_lq_cnt, &ix->ws_lq_off, &ix->ws_lq_cursor, &ix->ws_leaf_queries,
+    DevBuf *more[] = {&ix->ws_emit_ucnt, &ix->ws_emit_v, &ix->ws_leaf_units, &ix->ws_unit_off, &ix->ws_q_leaves, &ix->ws_q_leaf_cnt, &ix->d_leaf_tile0, &ix->ws_units, &ix->d_tiles, &ix->ws_lq_off, &ix->ws_lq_cursor, &ix->ws_leaf_queries,
                       &ix->ws_seed_cand, &ix->ws_seed_cnt, &ix->ws_seed_ids, &ix->ws_seed_scores, &ix->ws_emit, &ix->ws_emit_cnt,
                       &ix->d_base16, &ix->ws_q16, &ix->d_base16n, &ix->ws_q16n, &ix->d_base16e, &ix->ws_q16e, &ix->ws_flag, &ix->ws_tau, &ix->ws_qc, &ix->d_slot_norm, &ix->ws_ovf, &ix->sub_q, &ix->sub_qids, &ix->sub_ids,
                       &ix->sub_scores, &ix->sub_ws[0], &ix->sub_ws[1], &ix->sub_ws[2], &ix->sub_ws[3], &ix->sub_ws[4], &ix->sub_ws[5]};
@@ -973,7 +973,12 @@ static void fill_rerank_params(dpf_index *ix, RerankParams &rp, const void *d_Qp
 static const int TICKET_COUNTERS = 16;
 static const size_t FLAG_BYTES = 128 + 2 * (size_t)TICKET_COUNTERS * 128;
 // the per-query forward counts sit behind them, so that one memset clears everything a batch starts from
-static int32_t *emit_cnt_of(const dpf_index *ix) { return (int32_t *)((char *)ix->ws_flag.p + FLAG_BYTES); }
+// Everything a batch starts from at zero sits in ONE buffer, cleared by one memset: the per-bucket incidence
+// histogram lq_cnt[num_leaves + 1] first (its size only changes with a fit), the flag block behind it.
+static size_t lq_cnt_bytes_of(const dpf_index *ix) { return ((size_t)(ix->num_leaves + 1) * 4 + 255) & ~(size_t)255; }
+static uint32_t *lq_cnt_of(const dpf_index *ix) { return (uint32_t *)ix->ws_flag.p; }
+static char *flag_block_of(const dpf_index *ix) { return (char *)ix->ws_flag.p + lq_cnt_bytes_of(ix); }
+static int32_t *emit_cnt_of(const dpf_index *ix) { return (int32_t *)(flag_block_of(ix) + FLAG_BYTES); }
 // Forwarded candidates a query's list holds before the gather path answers the query instead.  The
 // handle starts at 8192 and doubles the lists (up to 65536) after a batch in which a list overflowed;
 // DPF_OPT_EMIT_CAP pins the value.
@@ -996,9 +1001,8 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     HIPCHECK(ix, ix->ws_raw.ensure((size_t)nq * 8));
     HIPCHECK(ix, ix->ws_bound.ensure((size_t)nq * 8));
     // (cleared sizes are whole 256-byte runs: one fill kernel each instead of a body and a tail)
-    const size_t lq_cnt_bytes = ((size_t)(nl + 1) * 4 + 255) & ~(size_t)255;
+    const size_t lq_cnt_bytes = lq_cnt_bytes_of(ix);
     const size_t flag_bytes = (FLAG_BYTES + (size_t)nq * 4 + 255) & ~(size_t)255;
-    HIPCHECK(ix, ix->ws_lq_cnt.ensure(lq_cnt_bytes));
     HIPCHECK(ix, ix->ws_lq_cursor.ensure((size_t)(nl + 1) * 4));
     HIPCHECK(ix, ix->ws_lq_off.ensure((size_t)(nl + 2) * 8));
     HIPCHECK(ix, ix->ws_seed_cand.ensure((size_t)nq * SEED_CAP * 4));
@@ -1006,7 +1010,7 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     HIPCHECK(ix, ix->ws_seed_ids.ensure((size_t)nq * k * 4));
     HIPCHECK(ix, ix->ws_seed_scores.ensure((size_t)nq * k * 8));
     HIPCHECK(ix, ix->ws_emit.ensure((size_t)nq * EMIT_CAP * 4));
-    HIPCHECK(ix, ix->ws_flag.ensure(flag_bytes));
+    HIPCHECK(ix, ix->ws_flag.ensure(lq_cnt_bytes + flag_bytes));
     HIPCHECK(ix, ix->ws_tau.ensure((size_t)nq * 4));
 
     if (ix->profiling) HIPCHECK(ix, hipEventRecord(ix->ev[0], stream));
@@ -1015,11 +1019,10 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
         if (hrc != DPF_OK) return hrc;
     }
     if (ix->profiling) HIPCHECK(ix, hipEventRecord(ix->ev[1], stream));
-    HIPCHECK(ix, hipMemsetAsync(ix->ws_lq_cnt.p, 0, lq_cnt_bytes, stream));
-    HIPCHECK(ix, hipMemsetAsync(ix->ws_flag.p, 0, flag_bytes, stream));
+    HIPCHECK(ix, hipMemsetAsync(ix->ws_flag.p, 0, lq_cnt_bytes + flag_bytes, stream));
     ProbeParams pp;
     fill_probe_params(ix, pp, d_qids, steps, handle_ws(ix));
-    pp.lq_cnt = ix->ws_lq_cnt.as<uint32_t>();
+    pp.lq_cnt = lq_cnt_of(ix);
     // the buckets each query reaches are remembered (up to a cap) so that the lists can be filled
     // without walking the forest again
     {
@@ -1032,7 +1035,7 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
         HIPCHECK(ix, ix->ws_q_leaf_cnt.ensure((size_t)nq * 4));
         pp.q_leaves = ix->ws_q_leaves.as<uint2>();
         pp.q_leaf_cnt = ix->ws_q_leaf_cnt.as<int32_t>();
-        pp.q_leaf_overflow = ix->ws_flag.as<int32_t>() + 1;
+        pp.q_leaf_overflow = (int32_t *)flag_block_of(ix) + 1;
     }
     launch_probe(0, pp, nq, stream);
     HIPCHECK(ix, ix->ws_unit_off.ensure((size_t)(nl + 2) * 8));
@@ -1043,15 +1046,15 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     const bool carried = ix->sizes_carried && !ix->opt_sync_sizes;
     const int64_t cap_pairs = std::min<int64_t>((int64_t)(ix->ws_leaf_queries.cap / 4), 0xfffffffell);
     const int64_t cap_units = std::min<int64_t>((int64_t)(ix->ws_units.cap / 16), 0xfffffffell);
-    int32_t *const flags = ix->ws_flag.as<int32_t>();
-    int64_t *const d_totals = (int64_t *)((char *)ix->ws_flag.p + 16);
-    launch_bucket_scans(ix->ws_lq_cnt.as<uint32_t>(), ix->d_leaf_tile0.as<uint32_t>(), nl, ix->ws_lq_off.as<int64_t>(),
+    int32_t *const flags = (int32_t *)flag_block_of(ix);
+    int64_t *const d_totals = (int64_t *)(flag_block_of(ix) + 16);
+    launch_bucket_scans(lq_cnt_of(ix), ix->d_leaf_tile0.as<uint32_t>(), nl, ix->ws_lq_off.as<int64_t>(),
                         ix->ws_unit_off.as<int64_t>(), d_totals, carried, cap_pairs, cap_units, flags,
                         ix->ws_lq_cursor.as<uint32_t>(), stream);
     int64_t pairs = 0, nunits = 0;
     bool lists_truncated = false;
     if (!carried) {
-        HIPCHECK(ix, hipMemcpyAsync(ix->pinned, ix->ws_flag.p, 32, hipMemcpyDeviceToHost, stream));   // flags + the two totals
+        HIPCHECK(ix, hipMemcpyAsync(ix->pinned, flags, 32, hipMemcpyDeviceToHost, stream));   // flags + the two totals
         HIPCHECK(ix, hipStreamSynchronize(stream));
         pairs = ix->pinned[2]; nunits = ix->pinned[3];
         lists_truncated = (int32_t)((uint64_t)ix->pinned[0] >> 32) != 0;
@@ -1088,12 +1091,15 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     HIPCHECK(ix, ix->ws_q16n.ensure((size_t)nq * 4));
     HIPCHECK(ix, ix->ws_q16e.ensure((size_t)nq * 4));
     HIPCHECK(ix, ix->ws_qc.ensure((size_t)nq * 16));
-    launch_rows_to_f16((const float *)qpad, ix->dpad, ix->cfg.dim, nq, ix->ws_q16.as<uint16_t>(), ix->ks16 * 32,
-                       ix->ws_q16n.as<float>(), ix->ws_q16e.as<float>(), stream);
-    launch_tau(ix->cfg.metric, ix->ws_seed_scores.as<double>(), ix->ws_seed_ids.as<int32_t>(), k, nq, ix->ws_q16n.as<float>(),
-               ix->ws_q16e.as<float>(), d_qids, ix->ks16, ix->ws_tau.as<int32_t>(), (float4 *)ix->ws_qc.p, stream);
+    {   // the conversion's last lane of every query row also writes the query's first threshold and scan record
+        TauParams tp;
+        tp.metric = ix->cfg.metric; tp.seed_scores = ix->ws_seed_scores.as<double>(); tp.seed_ids = ix->ws_seed_ids.as<int32_t>();
+        tp.k = k; tp.qids = d_qids; tp.tau = ix->ws_tau.as<int32_t>(); tp.qc = (float4 *)ix->ws_qc.p;
+        launch_rows_to_f16((const float *)qpad, ix->dpad, ix->cfg.dim, nq, ix->ws_q16.as<uint16_t>(), ix->ks16 * 32,
+                           ix->ws_q16n.as<float>(), ix->ws_q16e.as<float>(), stream, &tp);
+    }
     if (!carried) HIPCHECK(ix, ix->ws_units.ensure((size_t)std::max<int64_t>(nunits + nunits / 2, 1024) * 16));
-    launch_units(ix->ws_lq_cnt.as<uint32_t>(), ix->ws_lq_off.as<int64_t>(), ix->d_leaf_tile0.as<uint32_t>(),
+    launch_units(lq_cnt_of(ix), ix->ws_lq_off.as<int64_t>(), ix->d_leaf_tile0.as<uint32_t>(),
                  (const uint4 *)ix->d_tiles.p, ix->nutiles, ix->ws_unit_off.as<int64_t>(), (uint4 *)ix->ws_units.p,
                  carried ? flags + 3 : nullptr, stream);
     HIPCHECK(ix, ix->ws_emit_v.ensure((size_t)nq * EMIT_CAP * 4));
@@ -1112,7 +1118,7 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     lp.units = (const uint4 *)ix->ws_units.p;
     lp.num_cus = ix->num_cus; lp.ks = ix->ks16;
     lp.num_counters = TICKET_COUNTERS;
-    lp.tickets = (unsigned int *)((char *)ix->ws_flag.p + 128);
+    lp.tickets = (unsigned int *)(flag_block_of(ix) + 128);
     // a first slice of the units, then thresholds refined from what it forwarded, then the rest
     const int first_permille = ix->opt_first_permille;
     int64_t n_first = std::min<int64_t>(nunits, nunits * first_permille / 1000);
@@ -1131,8 +1137,9 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     launch_leafscan(ix->cfg.metric, lp, stream);
     if (ix->profiling) HIPCHECK(ix, hipEventRecord(ix->ev_scan[3], stream));
     HIPCHECK(ix, ix->ws_ovf.ensure((size_t)nq * 4));
-    launch_overflow_list(emit_cnt_of(ix), nq, EMIT_CAP, flags, ix->ws_ovf.as<int32_t>(), stream);
-    HIPCHECK(ix, hipMemcpyAsync(ix->pinned + 4, ix->ws_flag.p, 32, hipMemcpyDeviceToHost, stream));
+    // one small kernel lists the overflowed queries and writes the batch's 32-byte record (flags + totals) straight
+    // into the pinned host words the host reads after the wait
+    launch_overflow_list(emit_cnt_of(ix), nq, EMIT_CAP, flags, ix->ws_ovf.as<int32_t>(), (int32_t *)(ix->pinned + 4), stream);
     HIPCHECK(ix, hipStreamSynchronize(stream));
     if (carried) {
         if ((int32_t)((uint64_t)ix->pinned[5] >> 32) != 0) {         // abandoned on the device: again, reading the sizes first
@@ -1573,7 +1580,7 @@ extern "C" int dpf_last_rerank_profile(dpf_index *ix, double *ms, int64_t *algor
         // its index, threshold and 16-byte record per (query, bucket) incidence; one (id, bound) pair
         // per forwarded candidate
         std::vector<uint32_t> c((size_t)ix->num_leaves);
-        HIPCHECK(ix, hipMemcpy(c.data(), ix->ws_lq_cnt.p, c.size() * 4, hipMemcpyDeviceToHost));
+        HIPCHECK(ix, hipMemcpy(c.data(), lq_cnt_of(ix), c.size() * 4, hipMemcpyDeviceToHost));
         int64_t touched_rows = 0;
         for (size_t l = 0; l < c.size(); l++)
             if (c[l]) touched_rows += ix->h_leaf_len[l];

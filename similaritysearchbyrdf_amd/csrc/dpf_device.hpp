@@ -76,7 +76,7 @@ struct LeafScanParams {
     const int32_t *qids;
     int32_t exclude_self;
     int32_t *tau;                // [nq] filter threshold (l2: radius, dot: product), order-preserving int encoding; tightened in flight
-    const float4 *qc;            // [nq] per-query record of the scan, written by k_tau
+    const float4 *qc;            // [nq] per-query record of the scan, written with the query rows' fp16 conversion
     int32_t k;
     int32_t *emit;               // [nq][emit_cap] forwarded ids
     float *emit_v;               // [nq][emit_cap] pessimistic score bound of each forwarded row
@@ -149,14 +149,26 @@ int leafscan_f16_steps(int dim);
 int leafscan_tile_rows(int ks);
 void launch_refine(int metric, const int32_t *emit, const float *emit_v, const int32_t *emit_cnt, int32_t cap, int k, int64_t nq,
                    const float *q16_err, int32_t *tau, hipStream_t stream);
+// what the conversion of a QUERY batch writes besides the fp16 rows: each query's first threshold (from the k-th
+// best exact score of its seed sample) and the 16-byte record the scan reads
+struct TauParams {
+    int metric = 1;
+    const double *seed_scores = nullptr;   // [nq][k]
+    const int32_t *seed_ids = nullptr;     // [nq][k]
+    int k = 0;
+    const int32_t *qids = nullptr;
+    int32_t *tau = nullptr;                // [nq]
+    float4 *qc = nullptr;                  // [nq]
+};
 void launch_rows_to_f16(const float *src, int64_t src_stride, int dim, int64_t n, uint16_t *dst, int dst_stride,
-                         float *norms, float *errs, hipStream_t stream);
-void launch_tau(int metric, const double *seed_scores, const int32_t *seed_ids, int k, int64_t nq, const float *q16_norm,
-                const float *q16_err, const int32_t *qids, int ks, int32_t *tau, float4 *qc, hipStream_t stream);
+                         float *norms, float *errs, hipStream_t stream, const TauParams *tau = nullptr);
 size_t unique_lists_lds(int32_t longest);
 void launch_unique_lists(int32_t *emit, const int32_t *emit_cnt, int32_t cap, int32_t longest, int32_t *unique_cnt, int64_t nq,
                          hipStream_t stream);
-void launch_overflow_list(const int32_t *emit_cnt, int64_t nq, int32_t cap, int32_t *flag, int32_t *list, hipStream_t stream);
+// flag[0] = overflowed lists (their queries in list[]), flag[2] = longest list; then the 32 bytes at `flag` (flags and
+// the two scan totals) are copied to host_record (pinned host memory)
+void launch_overflow_list(const int32_t *emit_cnt, int64_t nq, int32_t cap, int32_t *flag, int32_t *list, int32_t *host_record,
+                          hipStream_t stream);
 void launch_gather_queries(const int32_t *list, int64_t n, const void *Q, int64_t row_bytes, const int32_t *qids, void *subQ,
                            int32_t *sub_qids, hipStream_t stream);
 void launch_scatter_results(const int32_t *list, int64_t n, int k, const int32_t *sub_ids, const double *sub_scores, int32_t *ids,

@@ -1618,12 +1618,31 @@ int leafscan_f16_steps(int dim)
     return ks <= 32 ? 32 : -1;
 }
 
+// First threshold and the per-query record the scan reads (see leafscan_chunks), written by the lane that finishes a
+// query row's conversion.  The exact k-th best score of the query's seed sample, moved to the safe side by the
+// conversion to fp32 (l2: up, dot: down); l2 stores the radius sqrt(k-th best squared distance) + |q - q~|.  A
+// query with fewer than k seeds starts without a threshold.
+__device__ __forceinline__ void write_tau(const TauParams &t, int64_t q, float qn, float qe, int stride)
+{
+    const int32_t kth_id = t.seed_ids[q * t.k + t.k - 1];
+    const double kth = t.seed_scores[q * t.k + t.k - 1];
+    const float c32 = leafscan_c32(stride);
+    float v;
+    if (t.metric == 1) v = kth_id < 0 ? HUGE_VALF : sqrtf(fmaxf((float)kth, 0.f) * 1.000001f) * 1.000001f + qe;
+    else v = kth_id < 0 ? -HUGE_VALF : (float)kth - fabsf((float)kth) * 1e-6f - 1e-30f;
+    t.tau[q] = enc_f32(v);
+    t.qc[q] = make_float4(t.metric == 1 ? 0.5f * qn * (1.0f - c32) : sqrtf(qn) * 1.00001f, qe, qn,
+                          __int_as_float(t.qids ? t.qids[q] : -1));
+}
+
 // fp32 rows (stride src_stride floats, `dim` meaningful) -> fp16 rows of dst_stride elements (a
 // multiple of 32), round to nearest even, zero padded; norms[r] = sum of the squares of the ROUNDED
 // elements of row r, accumulated in fp32; errs[r] = an upper bound of |row - rounded row| (the
 // element differences are exact in fp32).  One lane converts 8 consecutive elements.
+template <bool TAU>
 __global__ void k_rows_to_f16(const float *__restrict__ src, int64_t src_stride, int dim, int64_t n,
-                               uint16_t *__restrict__ dst, int dst_stride, float *__restrict__ norms, float *__restrict__ errs)
+                               uint16_t *__restrict__ dst, int dst_stride, float *__restrict__ norms, float *__restrict__ errs,
+                               TauParams tp)
 {
     const int per_row = dst_stride >> 3;                  // lanes per row: a power of two up to 64
     const int64_t total = n * per_row;
@@ -1656,13 +1675,18 @@ __global__ void k_rows_to_f16(const float *__restrict__ src, int64_t src_stride,
         *(uint4 *)(dst + i * 8) = w;
     }
     for (int m = 1; m < per_row; m <<= 1) { ss += __shfl_xor(ss, m); ee += __shfl_xor(ee, m); }   // rows never straddle a wave
-    if (live && c0 == 0) { norms[r] = ss; errs[r] = sqrtf(ee * 1.0001f) * 1.00001f; }
+    if (live && c0 == 0) {
+        const float er = sqrtf(ee * 1.0001f) * 1.00001f;
+        norms[r] = ss; errs[r] = er;
+        if (TAU) write_tau(tp, r, ss, er, dst_stride);
+    }
 }
 // The same for rows of more than 512 elements (or a stride that is no power of two): one wave per row,
 // a lane converts 8 consecutive elements of every 512.
+template <bool TAU>
 __global__ __launch_bounds__(256) void k_rows_to_f16_long(const float *__restrict__ src, int64_t src_stride, int dim, int64_t n,
                                                           uint16_t *__restrict__ dst, int dst_stride, float *__restrict__ norms,
-                                                          float *__restrict__ errs)
+                                                          float *__restrict__ errs, TauParams tp)
 {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1690,53 +1714,28 @@ __global__ __launch_bounds__(256) void k_rows_to_f16_long(const float *__restric
         *(uint4 *)(dst + r * dst_stride + c0) = w;
     }
     for (int m = 1; m < 64; m <<= 1) { ss += __shfl_xor(ss, m); ee += __shfl_xor(ee, m); }
-    if (lane == 0) { norms[r] = ss; errs[r] = sqrtf(ee * 1.0001f) * 1.00001f; }
+    if (lane == 0) {
+        const float er = sqrtf(ee * 1.0001f) * 1.00001f;
+        norms[r] = ss; errs[r] = er;
+        if (TAU) write_tau(tp, r, ss, er, dst_stride);
+    }
 }
 void launch_rows_to_f16(const float *src, int64_t src_stride, int dim, int64_t n, uint16_t *dst, int dst_stride,
-                         float *norms, float *errs, hipStream_t stream)
+                         float *norms, float *errs, hipStream_t stream, const TauParams *tau)
 {
     if (n <= 0) return;
     const int per_row = dst_stride / 8;
+    const TauParams tp = tau ? *tau : TauParams();
     if (per_row > 64 || (per_row & (per_row - 1)) != 0) {
-        hipLaunchKernelGGL(k_rows_to_f16_long, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, src, src_stride, dim, n, dst,
-                           dst_stride, norms, errs);
+        const dim3 grid((unsigned)((n + 3) / 4)), block(256);
+        if (tau) hipLaunchKernelGGL((k_rows_to_f16_long<true>), grid, block, 0, stream, src, src_stride, dim, n, dst, dst_stride, norms, errs, tp);
+        else hipLaunchKernelGGL((k_rows_to_f16_long<false>), grid, block, 0, stream, src, src_stride, dim, n, dst, dst_stride, norms, errs, tp);
         return;
     }
     const int64_t total = n * (dst_stride / 8);
-    hipLaunchKernelGGL(k_rows_to_f16, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, src, src_stride, dim, n,
-                       dst, dst_stride, norms, errs);
-}
-
-// First thresholds and the per-query record the scan reads (see leafscan_chunks).  The exact k-th best
-// score of each query's seed sample, moved to the safe side by the conversion to fp32 (l2: up, dot:
-// down); l2 stores the radius sqrt(k-th best squared distance) + |q - q~|.  A query with fewer than
-// k seeds starts without a threshold.
-template <int METRIC>
-__global__ void k_tau(const double *__restrict__ seed_scores, const int32_t *__restrict__ seed_ids, int k, int64_t nq,
-                      const float *__restrict__ q16_norm, const float *__restrict__ q16_err, const int32_t *__restrict__ qids,
-                      int stride, int32_t *__restrict__ tau, float4 *__restrict__ qc)
-{
-    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= nq) return;
-    const int32_t kth_id = seed_ids[q * k + k - 1];
-    const double kth = seed_scores[q * k + k - 1];
-    const float qn = q16_norm[q], qe = q16_err[q];
-    const float c32 = leafscan_c32(stride);
-    float t;
-    if (METRIC == 1) t = kth_id < 0 ? HUGE_VALF : sqrtf(fmaxf((float)kth, 0.f) * 1.000001f) * 1.000001f + qe;
-    else t = kth_id < 0 ? -HUGE_VALF : (float)kth - fabsf((float)kth) * 1e-6f - 1e-30f;
-    tau[q] = enc_f32(t);
-    qc[q] = make_float4(METRIC == 1 ? 0.5f * qn * (1.0f - c32) : sqrtf(qn) * 1.00001f, qe, qn,
-                        __int_as_float(qids ? qids[q] : -1));
-}
-
-void launch_tau(int metric, const double *seed_scores, const int32_t *seed_ids, int k, int64_t nq, const float *q16_norm,
-                const float *q16_err, const int32_t *qids, int ks, int32_t *tau, float4 *qc, hipStream_t stream)
-{
-    if (nq <= 0) return;
-    dim3 grid((unsigned)((nq + 255) / 256)), block(256);
-    if (metric == 0) hipLaunchKernelGGL((k_tau<0>), grid, block, 0, stream, seed_scores, seed_ids, k, nq, q16_norm, q16_err, qids, ks * 32, tau, qc);
-    else hipLaunchKernelGGL((k_tau<1>), grid, block, 0, stream, seed_scores, seed_ids, k, nq, q16_norm, q16_err, qids, ks * 32, tau, qc);
+    const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    if (tau) hipLaunchKernelGGL((k_rows_to_f16<true>), grid, block, 0, stream, src, src_stride, dim, n, dst, dst_stride, norms, errs, tp);
+    else hipLaunchKernelGGL((k_rows_to_f16<false>), grid, block, 0, stream, src, src_stride, dim, n, dst, dst_stride, norms, errs, tp);
 }
 
 void launch_leafscan(int metric, const LeafScanParams &p, hipStream_t stream)
@@ -1753,23 +1752,34 @@ void launch_leafscan(int metric, const LeafScanParams &p, hipStream_t stream)
 // rows per tile of the scan for rows of `ks` fp16 steps
 int leafscan_tile_rows(int ks) { return ks > 24 ? 16 : 64; }
 
-// flag[0] = number of queries whose forward list overflowed, their indices in list[];
-// flag[2] = the longest forward list of the batch
-__global__ void k_overflow_list(const int32_t *__restrict__ emit_cnt, int64_t nq, int32_t cap, int32_t *flag, int32_t *__restrict__ list)
+// flag[0] = number of queries whose forward list overflowed, their indices in list[]; flag[2] = the longest forward
+// list of the batch.  One workgroup (the batch's counts are a few tens of KB); its last act is to copy the 32-byte
+// record at flag[] (four flag words, two scan totals) into pinned host memory, where the host reads it after its wait
+// on the stream: no separate device-to-host copy.
+__global__ __launch_bounds__(1024) void k_overflow_list(const int32_t *__restrict__ emit_cnt, int64_t nq, int32_t cap, int32_t *flag,
+                                                        int32_t *__restrict__ list, int32_t *__restrict__ host_record)
 {
-    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int32_t c = q < nq ? emit_cnt[q] : 0;
-    if (c > cap) list[atomicAdd(flag, 1)] = (int32_t)q;
-    int32_t m = c;
+    int32_t m = 0;
+    for (int64_t q = threadIdx.x; q < nq; q += 1024) {
+        const int32_t c = emit_cnt[q];
+        if (c > cap) list[atomicAdd(flag, 1)] = (int32_t)q;
+        m = max(m, c);
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
     if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(flag + 2, m);
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        host_record[threadIdx.x] = __hip_atomic_load(flag + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence_system();
+    }
 }
 
-void launch_overflow_list(const int32_t *emit_cnt, int64_t nq, int32_t cap, int32_t *flag, int32_t *list, hipStream_t stream)
+void launch_overflow_list(const int32_t *emit_cnt, int64_t nq, int32_t cap, int32_t *flag, int32_t *list, int32_t *host_record,
+                          hipStream_t stream)
 {
-    if (nq <= 0) return;
-    hipLaunchKernelGGL(k_overflow_list, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, stream, emit_cnt, nq, cap, flag, list);
+    hipLaunchKernelGGL(k_overflow_list, dim3(1), dim3(1024), 0, stream, emit_cnt, nq, cap, flag, list, host_record);
 }
 
 // The queries named in list[] copied out as a batch of their own (16-byte pieces of the padded rows,

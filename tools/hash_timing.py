@@ -16,7 +16,10 @@ params = synthetic.make_family(dim, table_num=10, permutation_num=3 if family ==
                                family_size=F, partition_bits=3, orthogonal=(family == "angle"))
 rng = np.random.default_rng(1)
 X = rng.standard_normal((n, dim), dtype=np.float32)
-for name, opt in (("exact vector-ALU kernel", 0), ("matrix-core projection", 1)):
+order = (("exact vector-ALU kernel", 0), ("matrix-core projection", 1))
+if len(sys.argv) > 5 and sys.argv[5] == "swap":
+    order = order[::-1]
+for name, opt in order:
     ix = DpfIndex(params, dtype=np.float32)
     ix.set_option("projection_min_rows", opt)
     ix.fit(X[:1000])
