@@ -78,6 +78,10 @@ typedef struct dpf_config {
     int32_t flags;            /* DPF_FLAG_* */
     int32_t table_begin;      /* table shard: this handle probes only tables          */
     int32_t table_end;        /* table_begin <= t < table_end; table_end <= 0 = all L */
+    int32_t subindex_group;   /* sub-index shard: of every table this handle probes only the sub-indexes p with
+                                 p % subindex_groups == subindex_group (the reference's own partitioning unit,
+                                 Partitioner.scala:27-64); subindex_groups <= 1 = all sub-indexes          */
+    int32_t subindex_groups;
     int64_t row_begin;        /* rerank shard: this handle scores only candidates  */
     int64_t row_end;          /* with row_begin <= id < row_end; row_end < 0 = all */
 } dpf_config;
@@ -225,6 +229,21 @@ int dpf_merge_topk_packed_device(dpf_index *ix, const void *in, int64_t part_byt
  * are reported through dpf_last_error(NULL). */
 int dpf_save(dpf_index *ix, const char *path);
 int dpf_load(const char *path, int32_t device, dpf_index **out);
+/* One shard of a saved index: the file (saved by a handle that held every row) is memory-mapped and only what the
+ * shard needs is copied to the device - the hashes of all ids (the replicated forest is rebuilt from them) and the
+ * rows [row_begin, row_end) - so a base larger than one GPU's memory is brought up rank by rank from one file, each
+ * rank naming its rows, tables and sub-index group.  `shard` supplies table_begin / table_end, subindex_group /
+ * subindex_groups, row_begin / row_end (its other fields are ignored; NULL = the shard the file was saved with). */
+int dpf_load_shard(const char *path, int32_t device, const dpf_config *shard, dpf_index **out);
+/* How a handle walks the forest for dpf_query_batch / dpf_query_topk*:
+ *   DPF_PROBE_FLIPS (default)  RandomDrawTreeMap.getSimilarWithStepWiseFaster (RDT:742-797): the single-bit flips
+ *                              of the hash, never the hash itself; what DensevectorRDFInit queries with;
+ *   DPF_PROBE_OWN              RandomDrawTreeMap.getSimilarWithStepWise(key, steps) (RDT:630-675): the hash itself
+ *                              only, in every sub-index within `steps`; what SparsevectorRDFInit's keyed batch query
+ *                              uses (SparsevectorRDFInit.scala:407).
+ * Unlike the dpf_set_option switches this changes results. */
+enum { DPF_PROBE_FLIPS = 0, DPF_PROBE_OWN = 1 };
+int dpf_set_probe_mode(dpf_index *ix, int32_t mode);
 /* The configuration a handle was created (or loaded) with. */
 int dpf_get_config(const dpf_index *ix, dpf_config *out);
 

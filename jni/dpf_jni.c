@@ -21,7 +21,7 @@
 
 #include "dpf.h"
 
-#define DPF_JNI_CONFIG_INTS 18      /* the int32 fields of dpf_config, in declaration order */
+#define DPF_JNI_CONFIG_INTS 20      /* the int32 fields of dpf_config, in declaration order */
 
 static dpf_index *handle_of(jlong h) { return (dpf_index *)(intptr_t)h; }
 
@@ -33,7 +33,7 @@ static void throw_dpf(JNIEnv *env, const dpf_index *ix, int rc)
     if (ex) (*env)->ThrowNew(env, ex, dpf_last_error(ix));
 }
 
-/* create(cfgInts[18], rowBegin, rowEnd): cfgInts holds the int32 fields of dpf_config in the order of
+/* create(cfgInts[20], rowBegin, rowEnd): cfgInts holds the int32 fields of dpf_config in the order of
  * Dpf.ConfigIntFields; every field is assigned by name, so a field added to the struct without a line
  * here stays zero and tests/test_jni_shim.py fails. */
 JNIEXPORT jlong JNICALL Java_mclab_gpu_Dpf_create(JNIEnv *env, jclass cls, jintArray jcfg, jlong rowBegin, jlong rowEnd)
@@ -41,7 +41,7 @@ JNIEXPORT jlong JNICALL Java_mclab_gpu_Dpf_create(JNIEnv *env, jclass cls, jintA
     (void)cls;
     if ((*env)->GetArrayLength(env, jcfg) != DPF_JNI_CONFIG_INTS) {
         jclass ex = (*env)->FindClass(env, "java/lang/IllegalArgumentException");
-        if (ex) (*env)->ThrowNew(env, ex, "Dpf.create: cfgInts must hold the 18 int fields of dpf_config");
+        if (ex) (*env)->ThrowNew(env, ex, "Dpf.create: cfgInts must hold the 20 int fields of dpf_config");
         return 0;
     }
     jint v[DPF_JNI_CONFIG_INTS];
@@ -66,6 +66,8 @@ JNIEXPORT jlong JNICALL Java_mclab_gpu_Dpf_create(JNIEnv *env, jclass cls, jintA
     cfg.flags = (int32_t)v[15];
     cfg.table_begin = (int32_t)v[16];
     cfg.table_end = (int32_t)v[17];
+    cfg.subindex_group = (int32_t)v[18];
+    cfg.subindex_groups = (int32_t)v[19];
     cfg.row_begin = (int64_t)rowBegin;
     cfg.row_end = (int64_t)rowEnd;
     dpf_index *ix = NULL;
@@ -255,6 +257,14 @@ JNIEXPORT void JNICALL Java_mclab_gpu_Dpf_counters(JNIEnv *env, jclass cls, jlon
         (*env)->SetLongArrayRegion(env, out, 0, 6, v);
     }
     throw_dpf(env, ix, rc);
+}
+
+/* setProbeMode(h, 0 = bit flips of the hash (RDT:742-797), 1 = the hash itself only (RDT:630-675)) */
+JNIEXPORT void JNICALL Java_mclab_gpu_Dpf_setProbeMode(JNIEnv *env, jclass cls, jlong h, jint mode)
+{
+    (void)cls;
+    dpf_index *ix = handle_of(h);
+    throw_dpf(env, ix, dpf_set_probe_mode(ix, (int32_t)mode));
 }
 
 JNIEXPORT void JNICALL Java_mclab_gpu_Dpf_save(JNIEnv *env, jclass cls, jlong h, jstring path)

@@ -17,6 +17,8 @@ object Dpf {
   val SelfCompat = 0          // reproduces RandomDrawTreeMap.java:982 (boxed-Integer reference inequality)
   val MetricDot = 0           // DensevectorRDFInit.scala:490
   val MetricL2 = 1
+  val ProbeFlips = 0          // RandomDrawTreeMap.getSimilarWithStepWiseFaster (RandomDrawTreeMap.java:742-797)
+  val ProbeOwn = 1            // RandomDrawTreeMap.getSimilarWithStepWise(key, steps) (RandomDrawTreeMap.java:630-675)
   val F32 = 0
   val F64 = 1
 
@@ -24,7 +26,7 @@ object Dpf {
   val ConfigIntFields: Array[String] = Array(
     "family", "dim", "num_functions", "num_tables", "chain_length", "partition_bits", "bucket_bits", "dir_node_size",
     "bucket_overflow", "type_of_index", "exclude_self", "metric", "top_k", "dtype", "device", "flags", "table_begin",
-    "table_end")
+    "table_end", "subindex_group", "subindex_groups")
 
   /** The array `create` takes, from named values; a missing name is 0 (flags, table shard = all tables). */
   def cfgInts(values: Map[String, Int]): Array[Int] = {
@@ -47,6 +49,7 @@ object Dpf {
   @native def rerank(h: Long, q: Array[Double], nq: Long, candOffsets: Array[Long], candIds: Array[Int], k: Int, ids: Array[Int], scores: Array[Double]): Unit
   @native def subindexDistribution(h: Long, out: Array[Double]): Unit
   @native def counters(h: Long, out: Array[Long]): Unit
+  @native def setProbeMode(h: Long, mode: Int): Unit
   @native def save(h: Long, path: String): Unit
   @native def load(path: String, device: Int): Long
 }

@@ -309,6 +309,8 @@ typedef struct {
 
 struct orc_index {
     orc_config cfg;
+    int32_t probe_own;            /* 1: RDT:630-675 instead of RDT:742-797 */
+    int32_t sub_group, sub_groups; /* sub-index shard filter (sub_groups <= 1: none) */
     int32_t seg, nbits, mask, max_level, bitmap_size, num_partitions;
     double *fns; double *b; int32_t *w; int32_t *chain_fn;
     double *part_fns; double *part_b; int32_t *part_w;
@@ -745,17 +747,33 @@ static void get_similar(orc_index *ix, int32_t table, int32_t key, const double 
     int32_t partition = orc_partition(ix, table, h);
     int32_t subs[256], nsubs = 0;
     orc_step_sub_indexes(partition, steps, ix->num_partitions, subs, &nsubs);
+    if (ix->probe_own) {
+        /* RDT:630-675 getSimilarWithStepWise(key, steps): the hash itself, in every sub-index within `steps`
+         * (what SparsevectorRDFInit.scala:407 queries with); no probe list, so no probe-count quirk either */
+        for (int32_t s = 0; s < nsubs; s++) {
+            if (ix->sub_groups > 1 && subs[s] % ix->sub_groups != ix->sub_group) continue;
+            const orc_engine *en = &ix->engines[(int64_t)table * ix->num_partitions + subs[s]];
+            if (!en->initialized) continue;
+            search_with_similarity(ix, en, key, en->root[seg], h, out);
+        }
+        return;
+    }
     int32_t nprobe = orc_probe_count(h);
     if (nprobe < 0) { *short_hash = 1; return; }
     for (int32_t i = 0; i < nprobe; i++) {
         int32_t pro = h ^ (int32_t)(1u << i);
         for (int32_t s = 0; s < nsubs; s++) {
+            /* not in the reference: the checker's view of a sub-index shard of this build's multi-GPU placement */
+            if (ix->sub_groups > 1 && subs[s] % ix->sub_groups != ix->sub_group) continue;
             const orc_engine *en = &ix->engines[(int64_t)table * ix->num_partitions + subs[s]];
             if (!en->initialized) continue;
             search_with_similarity(ix, en, key, en->root[seg], pro, out);
         }
     }
 }
+
+void orc_set_probe_own(orc_index *ix, int32_t on) { ix->probe_own = on != 0; }
+void orc_set_subindex_shard(orc_index *ix, int32_t group, int32_t groups) { ix->sub_group = group; ix->sub_groups = groups; }
 
 int64_t orc_get_similar(orc_index *ix, int32_t table, int32_t key, const double *v,
                         int32_t steps, int32_t *out, int64_t cap)

@@ -142,4 +142,10 @@ void orc_fitted_hashes(const orc_index *ix, int32_t table, int32_t *hashes, int3
 #ifdef __cplusplus
 }
 #endif
+/* RDT:630-675 (the keyed walk of SparsevectorRDFInit.scala:407) instead of RDT:742-797 for every later query */
+void orc_set_probe_own(orc_index *ix, int32_t on);
+/* restricts every later query to the sub-indexes p with p % groups == group (a shard of this build's multi-GPU
+ * placement; the reference has no such call) */
+void orc_set_subindex_shard(orc_index *ix, int32_t group, int32_t groups);
+
 #endif

@@ -100,6 +100,10 @@ def lib():
     L.orc_topk.argtypes = [C.c_void_p, dp, C.c_int64, i64p, ip, C.c_int32, C.c_int32, C.c_int32, ip, dp]
     L.orc_table_stats.restype = None
     L.orc_table_stats.argtypes = [C.c_void_p, C.c_int32, i64p, i64p, i64p]
+    L.orc_set_probe_own.restype = None
+    L.orc_set_probe_own.argtypes = [C.c_void_p, C.c_int32]
+    L.orc_set_subindex_shard.restype = None
+    L.orc_set_subindex_shard.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
     L.orc_fitted_hashes.restype = None
     L.orc_fitted_hashes.argtypes = [C.c_void_p, C.c_int32, ip, ip]
     _lib = L
@@ -173,6 +177,13 @@ class OracleIndex:
             self.close()
         except Exception:
             pass
+
+    def set_probe_own(self, on):
+        """True: later queries walk the hash itself only (RandomDrawTreeMap.java:630-675)."""
+        self.lib.orc_set_probe_own(self.h, 1 if on else 0)
+
+    def set_subindex_shard(self, group, groups):
+        self.lib.orc_set_subindex_shard(self.h, group, groups)
 
     def hash(self, table, v):
         v = _f64(v)

@@ -24,7 +24,7 @@ class DpfConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "family", "dim", "num_functions", "num_tables", "chain_length", "partition_bits",
         "bucket_bits", "dir_node_size", "bucket_overflow", "type_of_index", "exclude_self",
-        "metric", "top_k", "dtype", "device", "flags", "table_begin", "table_end")] + [
+        "metric", "top_k", "dtype", "device", "flags", "table_begin", "table_end", "subindex_group", "subindex_groups")] + [
         ("row_begin", C.c_int64), ("row_end", C.c_int64)]
 
 
@@ -48,6 +48,7 @@ EXPORTS = (
     "dpf_query_topk", "dpf_query_topk_device", "dpf_rerank", "dpf_merge_topk_device", "dpf_merge_topk_packed_device",
     "dpf_subindex_distribution", "dpf_get_stats", "dpf_last_rerank_profile", "dpf_set_profiling",
     "dpf_save", "dpf_load", "dpf_get_config", "dpf_snapshot_sizes", "dpf_snapshot_copy", "dpf_set_option", "dpf_query_topk_device_static",
+    "dpf_load_shard", "dpf_set_probe_mode",
 )
 
 # dpf_set_option keys (include/dpf.h)
@@ -119,6 +120,10 @@ def lib():
     L.dpf_save.argtypes = [vp, C.c_char_p]
     L.dpf_load.restype = C.c_int
     L.dpf_load.argtypes = [C.c_char_p, C.c_int32, C.POINTER(vp)]
+    L.dpf_load_shard.restype = C.c_int
+    L.dpf_load_shard.argtypes = [C.c_char_p, C.c_int32, C.POINTER(DpfConfig), C.POINTER(vp)]
+    L.dpf_set_probe_mode.restype = C.c_int
+    L.dpf_set_probe_mode.argtypes = [vp, C.c_int32]
     L.dpf_snapshot_sizes.restype = C.c_int
     L.dpf_snapshot_sizes.argtypes = [vp, i64p]
     L.dpf_snapshot_copy.restype = C.c_int
@@ -156,7 +161,7 @@ class DpfIndex:
     """
 
     def __init__(self, params, metric="dot", top_k=10, dtype=np.float32, device=0,
-                 row_begin=0, row_end=-1, table_begin=0, table_end=0):
+                 row_begin=0, row_end=-1, table_begin=0, table_end=0, subindex_group=0, subindex_groups=0):
         self.L_ = lib()
         p = params
         fns = _f64(p["fns"])
@@ -172,7 +177,7 @@ class DpfIndex:
             type_of_index=TYPE_OF_INDEX[p.get("type_of_index", "original")],
             exclude_self=SELF[p.get("exclude_self", "compat")], metric=METRIC[metric], top_k=top_k,
             dtype=DTYPE[self.np_dtype], device=device, flags=int(p.get('flags', 0)), table_begin=table_begin, table_end=table_end,
-            row_begin=row_begin, row_end=row_end)
+            subindex_group=subindex_group, subindex_groups=subindex_groups, row_begin=row_begin, row_end=row_end)
         self.dim, self.L, self.pb, self.top_k = d, Lt, pb, top_k
         self.h = C.c_void_p()
         rc = self.L_.dpf_create(C.byref(self.cfg), C.byref(self.h))
@@ -197,12 +202,20 @@ class DpfIndex:
         self._check(self.L_.dpf_save(self.h, os.fsencode(path)))
 
     @classmethod
-    def load(cls, path, device=-1):
-        """A handle equal to the one `save` was called on; device < 0 keeps the saved ordinal."""
+    def load(cls, path, device=-1, **shard):
+        """A handle equal to the one `save` was called on; device < 0 keeps the saved ordinal.  With shard keywords
+        (row_begin, row_end, table_begin, table_end, subindex_group, subindex_groups) only that shard of the saved
+        index is brought up (dpf_load_shard)."""
         self = cls.__new__(cls)
         self.L_ = lib()
         self.h = C.c_void_p()
-        rc = self.L_.dpf_load(os.fsencode(path), device, C.byref(self.h))
+        if shard:
+            sh = DpfConfig(row_begin=shard.get("row_begin", 0), row_end=shard.get("row_end", -1),
+                           table_begin=shard.get("table_begin", 0), table_end=shard.get("table_end", 0),
+                           subindex_group=shard.get("subindex_group", 0), subindex_groups=shard.get("subindex_groups", 0))
+            rc = self.L_.dpf_load_shard(os.fsencode(path), device, C.byref(sh), C.byref(self.h))
+        else:
+            rc = self.L_.dpf_load(os.fsencode(path), device, C.byref(self.h))
         if rc != 0:
             raise DpfError(rc, self.L_.dpf_last_error(None).decode())
         self.cfg = DpfConfig()
@@ -310,6 +323,10 @@ class DpfIndex:
     def set_option(self, name, value):
         """Tuning / test switches of this handle (dpf_set_option); none changes a result."""
         self._check(self.L_.dpf_set_option(self.h, OPTION[name], int(value)))
+
+    def set_probe_mode(self, mode):
+        """"flips" (RandomDrawTreeMap.java:742-797, default) or "own" (the keyed walk, RandomDrawTreeMap.java:630-675)."""
+        self._check(self.L_.dpf_set_probe_mode(self.h, {"flips": 0, "own": 1}[mode]))
 
     def set_profiling(self, on):
         self._check(self.L_.dpf_set_profiling(self.h, 1 if on else 0))

@@ -13,6 +13,11 @@
 #include <thread>
 #include <vector>
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include "../../include/dpf.h"
 #include "dpf_device.hpp"
 #include "dpf_build.hpp"
@@ -169,6 +174,7 @@ struct dpf_index {
     int64_t last_nq = 0;
     int32_t last_k = 0;
     bool last_valid = false;
+    int32_t probe_mode = DPF_PROBE_FLIPS;             // dpf_set_probe_mode
     unsigned char *scratch_ptr = nullptr;             // this device's copy of the static scratch array
     // dpf_set_option values (0 / default = the library's own choice)
     int32_t opt_emit_cap = 0, opt_bucket_list_cap = 0, opt_first_permille = 100, opt_seed_cap = 256;
@@ -231,6 +237,11 @@ extern "C" int dpf_create(const dpf_config *cfg, dpf_index **out)
     else if (cfg->exclude_self < 0 || cfg->exclude_self > 2) why = "unknown exclude_self mode";
     else if (cfg->table_begin < 0 || cfg->table_begin > cfg->num_tables || cfg->table_end > cfg->num_tables ||
              (cfg->table_end > 0 && cfg->table_end < cfg->table_begin)) why = "table shard outside [0, num_tables]";
+    if (why.empty() && !(cfg->flags & DPF_FLAG_HASH_ONLY) && cfg->partition_bits > 5)
+        why = "partition_bits must be at most 5 (32 sub-indexes per table)";
+    if (why.empty() && cfg->subindex_groups > 1 &&
+        (cfg->subindex_group < 0 || cfg->subindex_group >= cfg->subindex_groups || cfg->subindex_groups > (1 << cfg->partition_bits)))
+        why = "sub-index shard outside [0, subindex_groups) or more groups than sub-indexes";
     if (!why.empty()) { delete ix; return fail(nullptr, DPF_EINVAL, "dpf_create: " + why); }
     if (cfg->family == DPF_FAMILY_PSTABLE && cfg->chain_length > 1024) { delete ix; return fail(nullptr, DPF_EINVAL, "dpf_create: chain_length too large"); }
     ix->elem = cfg->dtype == DPF_F32 ? 4 : 8;
@@ -665,7 +676,7 @@ extern "C" int dpf_fit(dpf_index *ix, const void *X, int64_t n)
 // itself is rebuilt on load (it is a pure function of the hashes).
 // ---------------------------------------------------------------------------
 namespace {
-const char SNAP_MAGIC[8] = {'D', 'P', 'F', 'S', 'N', 'A', 'P', '1'};
+const char SNAP_MAGIC[8] = {'D', 'P', 'F', 'S', 'N', 'A', 'P', '2'};
 
 struct FileW {
     FILE *f; bool ok = true;
@@ -728,73 +739,124 @@ extern "C" int dpf_save(dpf_index *ix, const char *path)
     return DPF_OK;
 }
 
-extern "C" int dpf_load(const char *path, int32_t device, dpf_index **out)
+namespace {
+// a read-only mapping of a snapshot file, walked with bounds checks
+struct MapR {
+    const unsigned char *base = nullptr;
+    size_t size = 0, at = 0;
+    bool ok = true;
+    const void *take(size_t n)
+    {
+        if (!ok || n > size - at) { ok = false; return nullptr; }
+        const void *p = base + at;
+        at += n;
+        return p;
+    }
+    template <typename T> void val(T &v) { const void *p = take(sizeof(T)); if (p) memcpy(&v, p, sizeof(T)); }
+    // a length-prefixed array: pointer into the mapping + element count
+    template <typename T> const T *vec(uint64_t &n)
+    {
+        n = 0;
+        val(n);
+        if (!ok || n > (size - at) / sizeof(T)) { ok = false; return nullptr; }
+        return (const T *)take((size_t)n * sizeof(T));
+    }
+};
+}  // namespace
+
+extern "C" int dpf_load_shard(const char *path, int32_t device, const dpf_config *shard, dpf_index **out)
 {
     if (!path || !out) return DPF_EINVAL;
     *out = nullptr;
-    FILE *f = fopen(path, "rb");
-    if (!f) return fail(nullptr, DPF_EINVAL, std::string("dpf_load: cannot open ") + path);
-    FileR r{f};
-    char magic[8];
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return fail(nullptr, DPF_EINVAL, std::string("dpf_load: cannot open ") + path);
+    struct stat sb;
+    if (fstat(fd, &sb) != 0 || sb.st_size < 16) { close(fd); return fail(nullptr, DPF_EINVAL, "dpf_load: not a snapshot file of this library version"); }
+    void *mapping = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (mapping == MAP_FAILED) return fail(nullptr, DPF_EINVAL, std::string("dpf_load: cannot map ") + path);
+    MapR r;
+    r.base = (const unsigned char *)mapping;
+    r.size = (size_t)sb.st_size;
+    dpf_index *ix = nullptr;
+    auto bail = [&](int code, const std::string &msg) {
+        munmap(mapping, (size_t)sb.st_size);
+        g_create_error = msg;
+        if (ix) dpf_destroy(ix);
+        return code;
+    };
+    const void *magic = r.take(8);
+    if (!magic || memcmp(magic, SNAP_MAGIC, 8) != 0 || memcmp(r.base + r.size - 8, SNAP_MAGIC, 8) != 0)
+        return bail(DPF_EINVAL, "dpf_load: not a snapshot file of this library version (or truncated)");
     dpf_config cfg{};
     int32_t si[32];
-    int64_t n = 0, base_rows = 0;
-    r.get(magic, 8);
-    if (!r.ok || memcmp(magic, SNAP_MAGIC, 8) != 0) { fclose(f); return fail(nullptr, DPF_EINVAL, "dpf_load: not a snapshot file of this library version"); }
-    r.val(cfg); r.get(si, sizeof(si)); r.val(n); r.val(base_rows);
-    if (!r.ok || n < 0 || base_rows < 0 || base_rows > n) { fclose(f); return fail(nullptr, DPF_EINVAL, "dpf_load: damaged header"); }
+    int64_t n = 0, saved_rows = 0;
+    r.val(cfg);
+    { const void *p = r.take(sizeof(si)); if (p) memcpy(si, p, sizeof(si)); }
+    r.val(n); r.val(saved_rows);
+    if (!r.ok || n < 0 || saved_rows < 0 || saved_rows > n) return bail(DPF_EINVAL, "dpf_load: damaged header");
+    const int64_t saved_begin = cfg.row_begin < 0 ? 0 : cfg.row_begin;       // first id of the rows the file holds
     if (device >= 0) cfg.device = device;
-    dpf_index *ix = nullptr;
+    if (shard) {
+        cfg.table_begin = shard->table_begin; cfg.table_end = shard->table_end;
+        cfg.subindex_group = shard->subindex_group; cfg.subindex_groups = shard->subindex_groups;
+        cfg.row_begin = shard->row_begin; cfg.row_end = shard->row_end;
+    }
     int rc = dpf_create(&cfg, &ix);
-    if (rc != DPF_OK) { fclose(f); return rc; }
-    auto bail = [&](int code, const std::string &msg) { fclose(f); g_create_error = msg; dpf_destroy(ix); return code; };
-    const uint64_t big = (uint64_t)1 << 40;
-    std::vector<double> fns, b, part_fns, part_b;
-    std::vector<int32_t> w, chain_fn, part_w, hh, hp;
-    r.vec(fns, big); r.vec(chain_fn, big); r.vec(b, big); r.vec(w, big);
-    r.vec(part_fns, big); r.vec(part_b, big); r.vec(part_w, big);
-    r.vec(hh, big); r.vec(hp, big);
+    if (rc != DPF_OK) { munmap(mapping, (size_t)sb.st_size); return rc; }
+    uint64_t n_fns, n_chain, n_b, n_w, n_pf, n_pb, n_pw, n_hh, n_hp;
+    const double *fns = r.vec<double>(n_fns);
+    const int32_t *chain_fn = r.vec<int32_t>(n_chain);
+    const double *b = r.vec<double>(n_b);
+    const int32_t *w = r.vec<int32_t>(n_w);
+    const double *part_fns = r.vec<double>(n_pf);
+    const double *part_b = r.vec<double>(n_pb);
+    const int32_t *part_w = r.vec<int32_t>(n_pw);
+    const int32_t *hh = r.vec<int32_t>(n_hh);
+    const int32_t *hp = r.vec<int32_t>(n_hp);
     const size_t F = (size_t)cfg.num_functions, d = (size_t)cfg.dim, L = (size_t)cfg.num_tables, m = (size_t)cfg.chain_length,
                  pb = (size_t)cfg.partition_bits;
-    if (!r.ok || fns.size() != F * d || chain_fn.size() != L * m || hh.size() != (size_t)n * L || hp.size() != (size_t)n * L ||
-        (cfg.family == DPF_FAMILY_PSTABLE && (b.size() != F || w.size() != F)) || (pb > 0 && part_fns.size() != L * pb * 32))
+    const size_t in_row = d * ix->elem;
+    if (!r.ok || n_fns != F * d || n_chain != L * m || n_hh != (size_t)n * L || n_hp != (size_t)n * L ||
+        (cfg.family == DPF_FAMILY_PSTABLE && (n_b != F || n_w != F)) || (pb > 0 && n_pf != L * pb * 32) ||
+        (pb > 0 && cfg.family == DPF_FAMILY_PSTABLE && (n_pb != L * pb || n_pw != L * pb)) ||
+        r.size - r.at != (size_t)saved_rows * in_row + 8)
         return bail(DPF_EINVAL, "dpf_load: damaged or truncated file");
-    if ((rc = dpf_set_hash_family(ix, fns.data(), b.empty() ? nullptr : b.data(), w.empty() ? nullptr : w.data(), chain_fn.data())) != DPF_OK ||
-        (pb > 0 && (rc = dpf_set_partitioner(ix, part_fns.data(), part_b.empty() ? nullptr : part_b.data(),
-                                             part_w.empty() ? nullptr : part_w.data())) != DPF_OK) ||
+    if ((rc = dpf_set_hash_family(ix, fns, n_b ? b : nullptr, n_w ? w : nullptr, chain_fn)) != DPF_OK ||
+        (pb > 0 && (rc = dpf_set_partitioner(ix, part_fns, n_pb ? part_b : nullptr, n_pw ? part_w : nullptr)) != DPF_OK) ||
         (rc = dpf_set_sampling_index(ix, si)) != DPF_OK)
         return bail(rc, std::string("dpf_load: ") + ix->err);
-    // resident rows
-    const size_t row_bytes = (size_t)ix->dpad * ix->elem, in_row = d * ix->elem;
-    hipError_t e = ix->d_base.ensure(std::max<size_t>((size_t)base_rows * row_bytes, 16));
+    // the rows of this handle's shard, streamed from the mapping through the staging buffer
+    const int64_t want_begin = ix->row_begin, want_end = std::min<int64_t>(ix->row_end, n);
+    const int64_t new_rows = std::max<int64_t>(0, want_end - want_begin);
+    if (new_rows > 0 && (want_begin < saved_begin || want_end > saved_begin + saved_rows))
+        return bail(DPF_EINVAL, "dpf_load: the file does not hold the rows of the requested shard (save from a handle that holds every row)");
+    const unsigned char *rows = r.base + r.at + (size_t)(want_begin - saved_begin) * in_row;
+    const size_t row_bytes = (size_t)ix->dpad * ix->elem;
+    hipError_t e = ix->d_base.ensure(std::max<size_t>((size_t)new_rows * row_bytes, 16));
     const int64_t batch = 1 << 16;
-    std::vector<char> flat((size_t)std::min<int64_t>(batch, std::max<int64_t>(base_rows, 1)) * in_row);
-    if (e == hipSuccess) e = ix->ws_stage.ensure(flat.size());
-    for (int64_t s0 = 0; s0 < base_rows && e == hipSuccess && r.ok; s0 += batch) {
-        const int64_t cnt = std::min(batch, base_rows - s0);
-        r.get(flat.data(), (size_t)cnt * in_row);
-        if (!r.ok) break;
-        e = hipMemcpy(ix->ws_stage.p, flat.data(), (size_t)cnt * in_row, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = ix->ws_stage.ensure(std::max<size_t>((size_t)std::min<int64_t>(batch, std::max<int64_t>(new_rows, 1)) * in_row, 16));
+    for (int64_t s0 = 0; s0 < new_rows && e == hipSuccess; s0 += batch) {
+        const int64_t cnt = std::min(batch, new_rows - s0);
+        e = hipMemcpy(ix->ws_stage.p, rows + (size_t)s0 * in_row, (size_t)cnt * in_row, hipMemcpyHostToDevice);
         if (e == hipSuccess)
             launch_copy_rows(cfg.dtype, ix->ws_stage.p, cnt, (int)d, (char *)ix->d_base.p + (size_t)s0 * row_bytes, ix->dpad, nullptr);
         if (e == hipSuccess) e = hipDeviceSynchronize();
     }
-    r.get(magic, 8);
+    // the hashes of every id, straight from the mapping; the host mirror is refreshed only on demand (dpf_save)
+    if (e == hipSuccess) e = ix->d_hashes.ensure(std::max<size_t>((size_t)n_hh * 4, 16));
+    if (e == hipSuccess) e = ix->d_parts.ensure(std::max<size_t>((size_t)n_hp * 4, 16));
+    if (e == hipSuccess && n_hh) e = hipMemcpy(ix->d_hashes.p, hh, (size_t)n_hh * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess && n_hp) e = hipMemcpy(ix->d_parts.p, hp, (size_t)n_hp * 4, hipMemcpyHostToDevice);
     if (e != hipSuccess) return bail(DPF_EHIP, std::string("dpf_load: ") + hipGetErrorString(e));
-    if (!r.ok || memcmp(magic, SNAP_MAGIC, 8) != 0) return bail(DPF_EINVAL, "dpf_load: damaged or truncated file");
-    fclose(f);
-    e = ix->d_hashes.ensure(std::max<size_t>(hh.size() * 4, 16));
-    if (e == hipSuccess) e = ix->d_parts.ensure(std::max<size_t>(hp.size() * 4, 16));
-    if (e == hipSuccess && !hh.empty()) e = hipMemcpy(ix->d_hashes.p, hh.data(), hh.size() * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess && !hp.empty()) e = hipMemcpy(ix->d_parts.p, hp.data(), hp.size() * 4, hipMemcpyHostToDevice);
-    if (e != hipSuccess) { g_create_error = std::string("dpf_load: ") + hipGetErrorString(e); dpf_destroy(ix); return DPF_EHIP; }
-    ix->h_hashes.swap(hh);
-    ix->h_parts.swap(hp);
-    ix->host_hashes_valid = true;
-    if ((rc = finish_fit(ix, n, base_rows)) != DPF_OK) { g_create_error = "dpf_load: " + ix->err; dpf_destroy(ix); return rc; }
+    munmap(mapping, (size_t)sb.st_size);
+    ix->host_hashes_valid = n == 0;
+    if ((rc = finish_fit(ix, n, new_rows)) != DPF_OK) { g_create_error = "dpf_load: " + ix->err; dpf_destroy(ix); return rc; }
     *out = ix;
     return DPF_OK;
 }
+
+extern "C" int dpf_load(const char *path, int32_t device, dpf_index **out) { return dpf_load_shard(path, device, nullptr, out); }
 
 static void snapshot_sizes(dpf_index *ix, int64_t *sizes)
 {
@@ -883,6 +945,13 @@ static void fill_probe_params(dpf_index *ix, ProbeParams &pp, const int32_t *d_q
     pp.steps = steps; pp.exclude_self = ix->cfg.exclude_self;
     pp.t_begin = ix->cfg.table_begin;
     pp.t_end = ix->cfg.table_end <= 0 ? g.num_tables : ix->cfg.table_end;
+    pp.sub_mask = 0xffffffffu;
+    if (ix->cfg.subindex_groups > 1) {
+        pp.sub_mask = 0u;
+        for (int s2 = 0; s2 < g.num_parts; s2++)
+            if (s2 % ix->cfg.subindex_groups == ix->cfg.subindex_group) pp.sub_mask |= 1u << s2;
+    }
+    pp.probe_own = ix->probe_mode == DPF_PROBE_OWN ? 1 : 0;
     pp.qids = d_qids;
     pp.hashes = w.hashes;
     pp.parts = w.parts;
@@ -1486,6 +1555,14 @@ extern "C" int dpf_set_option(dpf_index *ix, int32_t option, int64_t value)
     default:
         return fail(ix, DPF_EINVAL, "dpf_set_option: unknown option");
     }
+}
+
+extern "C" int dpf_set_probe_mode(dpf_index *ix, int32_t mode)
+{
+    if (!ix) return DPF_EINVAL;
+    if (mode != DPF_PROBE_FLIPS && mode != DPF_PROBE_OWN) return fail(ix, DPF_EINVAL, "dpf_set_probe_mode: unknown mode");
+    ix->probe_mode = mode;
+    return DPF_OK;
 }
 
 extern "C" int dpf_set_profiling(dpf_index *ix, int32_t on)

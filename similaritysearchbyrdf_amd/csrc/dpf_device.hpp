@@ -36,6 +36,8 @@ struct ProbeParams {
     int32_t L, pb, bucket_bits, seg, nbits, dns, max_level;
     int32_t steps, exclude_self;
     int32_t t_begin, t_end;   // table shard probed by this handle
+    uint32_t sub_mask = 0xffffffffu;   // sub-indexes this handle probes (bit p = sub-index p)
+    int32_t probe_own = 0;    // 1: walk the unflipped hash only (RDT:630-675) instead of its bit flips (RDT:742-797)
     // query batch
     const int32_t *qids;      // [nq] or nullptr
     const int32_t *hashes;    // [nq][L]

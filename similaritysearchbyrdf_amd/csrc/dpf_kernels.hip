@@ -293,8 +293,9 @@ __global__ __launch_bounds__(1024) void k_probe(ProbeParams p)
                 if (t >= p.t_end) continue;
                 const uint32_t h = (uint32_t)p.hashes[q * p.L + t];
                 part[x] = p.parts[q * p.L + t];
-                // RDT:753: 32 - numberOfLeadingZeros(h) - 4 probes; negative for 0 <= h < 8
-                nprobe[x] = 32 - (h ? __clz(h) : 32) - 4;
+                // RDT:753: 32 - numberOfLeadingZeros(h) - 4 probes; negative for 0 <= h < 8.  The keyed walk
+                // (RDT:630-675) has no probe list: it looks up the hash itself, whatever its value.
+                nprobe[x] = p.probe_own ? 1 : 32 - (h ? __clz(h) : 32) - 4;
                 if (nprobe[x] <= 0) {
                     if (nprobe[x] < 0 && lane == 0 && c == 0 && MODE == 0) atomicAdd(p.short_hash_events, 1ull);
                     continue;
@@ -302,7 +303,7 @@ __global__ __launch_bounds__(1024) void k_probe(ProbeParams p)
                 roots[x] = p.roots + ((size_t)t * P) * p.seg + (h >> p.bucket_bits);
                 // the sub-indexes within `steps` bit flips of the query's own
                 for (int s2 = 0; s2 < P; s2++)
-                    if (__popc((uint32_t)(s2 ^ part[x])) <= p.steps) submask[x] |= 1u << s2;
+                    if (__popc((uint32_t)(s2 ^ part[x])) <= p.steps && ((p.sub_mask >> s2) & 1u)) submask[x] |= 1u << s2;
                 // lane 31 of each half walks the unflipped hash: it is not a probe (RDT:753-758),
                 // it only names the query's own bucket for the collapse below
                 key[x] = i == 31 ? h : h ^ (1u << i);
@@ -322,7 +323,7 @@ __global__ __launch_bounds__(1024) void k_probe(ProbeParams p)
                     }
                     sw[x][0] = half ? sub[1] : sub[0];
                     sw[x][1] = half ? sub[3] : sub[2];
-                    const bool act = i < nprobe[x] || (i == 31 && nprobe[x] > 0);
+                    const bool act = p.probe_own ? (i == 31 && nprobe[x] > 0) : (i < nprobe[x] || (i == 31 && nprobe[x] > 0));
 #pragma unroll
                     for (int k = 0; k < 2; k++) {
                         leaf[x][k] = NO_LEAF;
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(1024) void k_probe(ProbeParams p)
 #pragma unroll
                     for (int k = 0; k < 2; k++) {
                         const uint32_t own = __shfl(leaf[x][k], (lane & 32) + 31);
-                        if (i == 31) leaf[x][k] = NO_LEAF;
+                        if (i == 31 && !p.probe_own) leaf[x][k] = NO_LEAF;
                         const unsigned long long same = __ballot(leaf[x][k] != NO_LEAF && leaf[x][k] == own) >> (lane & 32);
                         if (leaf[x][k] == own && (same & ((1ull << i) - 1ull) & 0xffffffffull)) leaf[x][k] = NO_LEAF;
                         own_hit[x][k] = leaf[x][k] != NO_LEAF && leaf[x][k] == own && sw[x][k] == part[x];

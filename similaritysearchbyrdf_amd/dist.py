@@ -21,6 +21,13 @@ then a merge by score, then id, with repeated ids taken once):
   the candidates inside its row shard.  Used for single-table forests, when the
   base rows do not fit one GPU, and on request (mode="rows").
 
+* "subindexes": everything replicated; QG query groups x SG sub-index groups,
+  rank r = (r // SG, r % SG) probes, in every table, only the sub-indexes p with
+  p % SG == its group - the reference's own partitioning unit
+  (Partitioner.scala:27-64: a second-level LSH assigns every hash to one of
+  2^partitionBits sub-indexes).  A steps-s query touches the sub-indexes within
+  s bit flips of its own, so the load per rank is even only on average.
+
 The reference is a single JVM process (its "distribution" is the in-process
 sub-index partitioning of Partitioner.scala:27-64), so there is no reference
 call pattern to mirror here.
@@ -142,27 +149,36 @@ class ShardedDpf:
     """One rank's share of a sharded index on its GPU (see the module docstring for the two modes)."""
 
     def __init__(self, params, n_total, metric="l2", top_k=10, dtype=np.float32, device=0, rank=0, world=1,
-                 group=None, mode=None, grid=None):
+                 group=None, mode=None, grid=None, load_from=None, num_tables=None, partition_bits=None):
+        """params: the hash family etc. (as DpfIndex takes); or, with load_from = the path of a file written by
+        DpfIndex.save from an unsharded handle, params may be None: every rank then brings up only its shard of
+        that file (dpf_load_shard; num_tables / partition_bits of the saved index must be given)."""
         from ._lib import DpfIndex
         self.rank, self.world, self.group, self.metric = rank, world, group, metric
-        L = num_tables_of(params)
+        L = num_tables_of(params) if params is not None else int(num_tables)
+        pb = int(params.get("partition_bits", 3)) if params is not None else int(partition_bits)
         self.mode = mode or ("tables" if world > 1 and L >= world else "rows")
-        if self.mode not in ("tables", "rows"):
-            raise ValueError("mode must be 'tables' or 'rows'")
-        # qg query groups x sg shard groups (table groups or row groups); rank r = (r // sg, r % sg)
-        self.qg, self.sg = grid or (grid_of(world, L) if self.mode == "tables" else rows_grid_of(world))
-        if self.qg * self.sg != world or (self.mode == "tables" and self.sg > L):
-            raise ValueError("grid %r does not cover %d ranks" % ((self.qg, self.sg), world))
+        if self.mode not in ("tables", "rows", "subindexes"):
+            raise ValueError("mode must be 'tables', 'rows' or 'subindexes'")
+        # qg query groups x sg shard groups (table, row or sub-index groups); rank r = (r // sg, r % sg)
+        self.qg, self.sg = grid or (rows_grid_of(world) if self.mode == "rows" else grid_of(world, L if self.mode == "tables" else 1 << pb))
+        limit = {"tables": L, "rows": max(n_total, 1), "subindexes": 1 << pb}[self.mode]
+        if self.qg * self.sg != world or self.sg > limit:
+            raise ValueError("grid %r does not cover %d ranks in mode %s" % ((self.qg, self.sg), world, self.mode))
+        self.lo, self.hi, self.t_lo, self.t_hi = 0, n_total, 0, L
+        shard = {}
         if self.mode == "tables":
-            self.lo, self.hi = 0, n_total
             self.t_lo, self.t_hi = table_bounds(L, self.sg, rank % self.sg)
-            self.index = DpfIndex(params, metric=metric, top_k=top_k, dtype=dtype, device=device,
-                                  table_begin=self.t_lo, table_end=self.t_hi)
-        else:
+            shard = dict(table_begin=self.t_lo, table_end=self.t_hi)
+        elif self.mode == "rows":
             self.lo, self.hi = shard_bounds(n_total, self.sg, rank % self.sg)
-            self.t_lo, self.t_hi = 0, L
-            self.index = DpfIndex(params, metric=metric, top_k=top_k, dtype=dtype, device=device,
-                                  row_begin=self.lo, row_end=self.hi)
+            shard = dict(row_begin=self.lo, row_end=self.hi)
+        elif self.sg > 1:
+            shard = dict(subindex_group=rank % self.sg, subindex_groups=self.sg)
+        if load_from is not None:
+            self.index = DpfIndex.load(load_from, device=device, **(shard or dict(row_begin=0, row_end=-1)))
+        else:
+            self.index = DpfIndex(params, metric=metric, top_k=top_k, dtype=dtype, device=device, **shard)
         self.tg = self.sg            # (older name)
         self._bufs = None
 

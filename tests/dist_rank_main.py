@@ -36,7 +36,7 @@ def main():
     dqid = torch.from_numpy(pick).to(dev)
     grids = {2: [(1, 2), (2, 1)], 4: [(1, 4), (2, 2), (4, 1)]}[world]
     checked = 0
-    for mode in ("rows", "tables"):
+    for mode in ("rows", "tables", "subindexes"):
         for grid in grids:
             for metric in ("l2", "dot"):
                 sh = ShardedDpf(params, n, metric=metric, top_k=k, dtype=np.float32, device=0, rank=rank, world=world,

@@ -25,4 +25,4 @@ def test_sharded_device_stage_two_ranks_on_one_gpu():
     res = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     text = res.stdout.decode(errors="replace")
     assert res.returncode == 0, text[-4000:]
-    assert "dist check ok: world 2, 16 sharded batches" in text, text[-2000:]
+    assert "dist check ok: world 2, 24 sharded batches" in text, text[-2000:]

@@ -837,3 +837,110 @@ def test_random_configurations(seed):
     assert_same_sets(fast.query_batch(pick, Q, steps=steps), (off, ids))
     want = orc.topk(Q64, off, ids, k=k, metric=metric)
     assert_topk_equal(fi, fs, want[0], want[1])
+
+
+@pytest.mark.parametrize("groups", [2, 3, 8])
+def test_subindex_shards_and_merge(groups):
+    # every handle holds everything but probes, in every table, only the sub-indexes of its group (the reference's own
+    # partitioning unit, Partitioner.scala:27-64); per handle the sets equal the oracle restricted the same way, their
+    # union is the whole set, and the merged top-k is the unsharded answer
+    import torch
+    params, X, Q, pick = make_problem(n=7000, nq=40, bucket_overflow=40, table_num=2, permutation_num=2)
+    orc = O.OracleIndex(params)
+    orc.fit(X.astype(np.float64))
+    Q64 = Q.astype(np.float64)
+    off, ids = orc.query_batch(pick, Q64, steps=1)
+    want = orc.topk(Q64, off, ids, k=10, metric="l2")
+    parts_ids, parts_sc, union = [], [], [set() for _ in range(40)]
+    for g in range(groups):
+        h = DpfIndex(params, metric="l2", subindex_group=g, subindex_groups=groups)
+        h.fit(X)
+        orc.set_subindex_shard(g, groups)
+        for steps in (0, 1, 3):
+            assert_same_sets(h.query_batch(pick, Q, steps=steps), orc.query_batch(pick, Q64, steps=steps))
+        so, si = h.query_batch(pick, Q, steps=1)
+        for q in range(40):
+            union[q] |= set(si[so[q]:so[q + 1]].tolist())
+        pi, ps = h.query_topk(pick, Q, steps=1, k=10)
+        assert h.stats()["last_path"] == 1
+        parts_ids.append(pi)
+        parts_sc.append(ps)
+    orc.set_subindex_shard(0, 1)
+    for q in range(40):
+        assert sorted(union[q]) == ids[off[q]:off[q + 1]].tolist()
+    dev = torch.device("cuda:0")
+    t_ids = torch.from_numpy(np.stack(parts_ids)).to(dev)
+    t_sc = torch.from_numpy(np.stack(parts_sc)).to(dev)
+    o_ids = torch.empty((40, 10), dtype=torch.int32, device=dev)
+    o_sc = torch.empty((40, 10), dtype=torch.float64, device=dev)
+    h.merge_topk_device(t_ids.data_ptr(), t_sc.data_ptr(), groups, 40, 10, o_ids.data_ptr(), o_sc.data_ptr())
+    torch.cuda.synchronize()
+    assert_topk_equal(o_ids.cpu().numpy(), o_sc.cpu().numpy(), want[0], want[1])
+    with pytest.raises(Exception):
+        DpfIndex(params, subindex_group=9, subindex_groups=9)      # more groups than the 8 sub-indexes
+
+
+@pytest.mark.parametrize("family,pb", [("angle", 3), ("pStable", 2), ("angle", 0)])
+def test_keyed_walk_probes_the_hash_itself(family, pb):
+    # RandomDrawTreeMap.getSimilarWithStepWise(key, steps) (RandomDrawTreeMap.java:630-675), the walk
+    # SparsevectorRDFInit's keyed batch query uses (SparsevectorRDFInit.scala:407): the query's own bucket in every
+    # sub-index within `steps`, no bit flips, no probe-count quirk
+    kw = dict(table_num=3, permutation_num=1, pstable_w=2) if family == "pStable" else dict(table_num=2, permutation_num=2)
+    params, X, Q, pick = make_problem(n=6000, nq=48, family=family, bucket_overflow=30, partition_bits=pb, n_clusters=10, **kw)
+    orc, gpu = both(params, X, metric="l2")
+    slow = DpfIndex(dict(params, flags=2), metric="l2")
+    slow.fit(X)
+    orc.set_probe_own(True)
+    for h in (gpu, slow):
+        h.set_probe_mode("own")
+    qids = pick.astype(np.int32)
+    qids[:4] = [0, 5, 127, 128]
+    Qm = Q.copy()
+    Qm[:4] = X[[0, 5, 127, 128]]
+    Q64 = Qm.astype(np.float64)
+    for steps in range(0, pb + 1):
+        want = orc.query_batch(qids, Q64, steps=steps)
+        assert_same_sets(gpu.query_batch(qids, Qm, steps=steps), want)
+        wi, ws = orc.topk(Q64, want[0], want[1], k=10, metric="l2")
+        fi, fs = gpu.query_topk(qids, Qm, steps=steps, k=10)
+        si, ss = slow.query_topk(qids, Qm, steps=steps, k=10)
+        assert np.array_equal(fi, si) and np.array_equal(fs, ss, equal_nan=True)
+        assert_topk_equal(fi, fs, wi, ws)
+    assert want[0][-1] > 0
+    # and back: the default walk again
+    orc.set_probe_own(False)
+    gpu.set_probe_mode("flips")
+    assert_same_sets(gpu.query_batch(qids, Qm, steps=1), orc.query_batch(qids, Q64, steps=1))
+
+
+def test_load_shards_of_a_saved_index(tmp_path):
+    # one file saved by an unsharded handle; row, table and sub-index shards brought up from it (memory-mapped, only
+    # the shard's rows copied) answer as handles fitted with the same shard do
+    params, X, Q, pick = make_problem(n=9000, nq=40, bucket_overflow=40, table_num=3, permutation_num=2)
+    whole = DpfIndex(params, metric="l2")
+    whole.fit(X)
+    path = str(tmp_path / "whole.dpf")
+    whole.save(path)
+    shards = [dict(row_begin=0, row_end=3000), dict(row_begin=3000, row_end=-1), dict(table_begin=2, table_end=5),
+              dict(subindex_group=1, subindex_groups=3), dict(row_begin=4000, row_end=8000, table_begin=0, table_end=3)]
+    for sh in shards:
+        a = DpfIndex.load(path, **sh)
+        b = DpfIndex(params, metric="l2", **sh)
+        b.fit(X)
+        assert a.stats()["base_bytes"] == b.stats()["base_bytes"]
+        for x, y in zip(a.snapshot(), b.snapshot()):
+            assert np.array_equal(x, y)
+        ao, ai = a.query_batch(pick, Q, steps=1)
+        bo, bi = b.query_batch(pick, Q, steps=1)
+        assert np.array_equal(ao, bo) and np.array_equal(ai, bi)
+        at, as_ = a.query_topk(pick, Q, steps=1, k=10)
+        bt, bs = b.query_topk(pick, Q, steps=1, k=10)
+        assert np.array_equal(at, bt) and np.array_equal(as_, bs, equal_nan=True)
+    # a shard file cannot serve rows it does not hold
+    part = DpfIndex.load(path, row_begin=0, row_end=3000)
+    ppath = str(tmp_path / "part.dpf")
+    part.save(ppath)
+    again = DpfIndex.load(ppath)
+    assert again.stats()["base_bytes"] == part.stats()["base_bytes"]
+    with pytest.raises(Exception):
+        DpfIndex.load(ppath, row_begin=2000, row_end=5000)

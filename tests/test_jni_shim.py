@@ -30,7 +30,7 @@ def header_config_fields():
 
 def test_shim_assigns_every_config_field_in_header_order():
     ints, longs = header_config_fields()
-    assert len(ints) == 18 and longs == ["row_begin", "row_end"]
+    assert len(ints) == 20 and longs == ["row_begin", "row_end"]
     c = _strip_c_comments(_read("jni", "dpf_jni.c"))
     assert int(re.search(r"#define DPF_JNI_CONFIG_INTS (\d+)", c).group(1)) == len(ints)
     assigned = re.findall(r"cfg\.(\w+) = \(int32_t\)v\[(\d+)\];", c)
