@@ -9,6 +9,7 @@
 //   mclab::lsh::LSH                        src/main/scala/mclab/lsh/LSH.scala:17-196
 //   mclab::deploy::LSHServer               src/main/scala/mclab/deploy/LSHServer.scala:5-24
 //   mclab::deploy::DensevectorRDFInit      src/main/scala/mclab/deploy/DensevectorRDFInit.scala:19-593
+//   mclab::deploy::SparsevectorRDFInit     src/main/scala/mclab/deploy/SparsevectorRDFInit.scala:20-593
 //
 // The reference is a JVM program; its Scala toolchain is not part of this build,
 // so the drop-in host layer is C++.  A JNI shim binds the same C ABI.
@@ -20,6 +21,7 @@
 #include <set>
 #include <stdexcept>
 #include <string>
+#include <tuple>
 #include <utility>
 #include <vector>
 
@@ -65,6 +67,12 @@ struct DenseVector {                                             // Vector.scala
     std::string toString() const;                                // "[v0,v1,...]"
 };
 
+struct SparseVector {                                            // Vector.scala:374-378
+    int vectorId = 0, size = 0;
+    std::vector<int> indices;
+    std::vector<double> values;
+};
+
 struct SparseTuple {                                             // (id, size, indices, values)
     int id = 0, size = 0;
     std::vector<int> indices;
@@ -74,6 +82,7 @@ struct SparseTuple {                                             // (id, size, i
 struct Vectors {
     static std::pair<int, std::vector<double>> parseDense(const std::string &line);   // Vector.scala:215-219
     static SparseTuple fromString(const std::string &line);                           // Vector.scala:162-175
+    static SparseTuple fromPythonString(const std::string &line);                     // Vector.scala:194-208
     static std::vector<double> fromStringDense(const std::string &line);              // Vector.scala:182-186
     static std::vector<int> analysisKNN(const std::string &line, int k);              // Vector.scala:284-293
 };
@@ -155,6 +164,39 @@ public:
     // CSR form of the batch result, for bindings that do not want std::set
     static void queryBatchCSR(const int32_t *qids, const double *Q, int64_t nq, int steps,
                               std::vector<int64_t> &offsets, std::vector<int32_t> &ids);
+    static dpf_index *handle();
+    static int64_t size();
+};
+
+// The same tables fed with SparseVectors (SparsevectorRDFInit.scala).  Needs LSHServer::isUseDense == false.
+class SparsevectorRDFInit {
+public:
+    using SparseVector = lsh::vector::SparseVector;
+    static void initializeRDFHashMap(const Config &conf);                                                 // Sparse:51
+    // both return the stored VALUES of every vector (not its dense form), as the reference does (Sparse:136,179)
+    static std::vector<std::vector<double>> newFastFit(const std::string &fileName, const Config &conf);  // Sparse:124
+    static std::vector<std::vector<double>> newMultiThreadFit(const std::string &fileName, const Config &conf);   // Sparse:158
+    // not in the reference: the same fit from vectors already in memory (ids = positions)
+    static void fitVectors(const std::vector<SparseVector> &vectors, const Config &conf);
+    // by key: RandomDrawTreeMap.getSimilarWithStepWise(key, steps), the hash of the key's stored vector only (Sparse:324, 407)
+    static std::vector<std::set<int>> NewMultiThreadQueryBatch(const std::vector<int> &queryArray, int steps = 0,
+                                                               int queryThreadNum = 5);
+    // Sparse:360: inserts the query vectors with fresh ids first, then queries them by key
+    static std::vector<std::set<int>> NewMultiThreadQueryBatch(const std::vector<SparseVector> &vectors, int steps,
+                                                               int queryThreadNum);
+    // with the vectors given: getSimilarWithStepWiseFaster, as the dense object (Sparse:529, 574)
+    static std::vector<std::set<int>> query(const std::vector<int> &queryKeyArray, const std::vector<SparseVector> &vectors,
+                                            int steps = 0, int queryThreadNum = 10);
+    static std::set<int> querySingleKey(int queryKey, const SparseVector &v, int steps = 0, int L = -1);          // Sparse:278
+    static std::vector<std::set<int>> queryBatch(const std::vector<int> &queryArray, const std::vector<SparseVector> &vectors,
+                                                 int steps, int L = -1);                                           // Sparse:300
+    static std::vector<std::set<int>> getTopKGroundTruth(const std::string &filename, int K);                     // Sparse:427
+    // (top-k ids per answered query, recall, milliseconds the lookup took)                                          Sparse:458
+    static std::tuple<std::vector<std::vector<int>>, double, long> topKAndPrecisionScore(
+        const std::vector<std::vector<double>> &allDenseVectors, const std::vector<std::set<int>> &groundTruth,
+        const Config &conf, int steps = 0);
+    static void clearAndClose();                                                                                   // Sparse:440
+    static std::pair<std::vector<double>, std::vector<double>> getDtAndHtNumDistribution();                       // Sparse:509
     static dpf_index *handle();
     static int64_t size();
 };

@@ -10,7 +10,9 @@
 #include <fstream>
 #include <iostream>
 #include <random>
+#include <chrono>
 #include <sstream>
+#include <tuple>
 
 #include "../../../include/dpf.h"
 
@@ -204,6 +206,34 @@ SparseTuple Vectors::fromString(const std::string &line_)
         if (!s.empty()) t.indices.push_back(to_int(trim(s)));
     std::string vals = p[2];
     size_t close = vals.find("])");
+    if (close != std::string::npos) vals.erase(close, 2);
+    for (const std::string &s : split(vals, ','))
+        if (!s.empty()) t.values.push_back(to_double(s));
+    return t;
+}
+
+// "[1, 3, [1, 2, 3], [1.0, 2.0, 3.0]]": spaces dropped, split on ",[" into id/size, indices, values
+SparseTuple Vectors::fromPythonString(const std::string &line_)            // Vector.scala:194-208
+{
+    const std::string line = strip_chars(line_, " \r\n");
+    std::vector<std::string> p;
+    size_t a = 0;
+    for (;;) {
+        size_t b = line.find(",[", a);
+        if (b == std::string::npos) { p.push_back(line.substr(a)); break; }
+        p.push_back(line.substr(a, b - a));
+        a = b + 2;
+    }
+    if (p.size() != 3) throw MclabError("cannot parse " + line_);
+    SparseTuple t;
+    std::vector<std::string> head = split(strip_chars(p[0], "["), ',');
+    if (head.size() != 2) throw MclabError("cannot parse " + line_);
+    t.id = to_int(head[0]);
+    t.size = to_int(head[1]);
+    for (const std::string &s : split(strip_chars(p[1], "]"), ','))
+        if (!s.empty()) t.indices.push_back(to_int(s));
+    std::string vals = p[2];
+    size_t close = vals.find("]]");
     if (close != std::string::npos) vals.erase(close, 2);
     for (const std::string &s : split(vals, ','))
         if (!s.empty()) t.values.push_back(to_double(s));
@@ -509,12 +539,16 @@ struct State {
     int64_t n = 0;
     std::vector<double> part_fns, part_b;      // what initializeRDFHashMap gave the partitioners
     std::vector<int32_t> part_w;
-} S;
+    std::vector<double> rows;                  // SparsevectorRDFInit: the fitted vectors, dense, for its keyed queries
+};
+State S;     // DensevectorRDFInit's tables
+State T;     // SparsevectorRDFInit's tables (the reference keeps the two objects apart too)
 
-void check(int rc, const char *what)
+void check(const State &st, int rc, const char *what)
 {
-    if (rc != DPF_OK) throw MclabError(std::string(what) + ": " + (S.ix ? dpf_last_error(S.ix) : dpf_last_error(nullptr)));
+    if (rc != DPF_OK) throw MclabError(std::string(what) + ": " + (st.ix ? dpf_last_error(st.ix) : dpf_last_error(nullptr)));
 }
+void check(int rc, const char *what) { check(S, rc, what); }
 
 int self_mode(const std::string &s)
 {
@@ -541,35 +575,35 @@ std::vector<double> flatten(const std::vector<lsh::vector::DenseVector> &v, size
     return flat;
 }
 
-void fit_rows(const double *X, int64_t n)
+void fit_rows(State &st, const double *X, int64_t n)
 {
-    if (S.store_f32) {
-        std::vector<float> f((size_t)n * S.dim);
+    if (st.store_f32) {
+        std::vector<float> f((size_t)n * st.dim);
         for (size_t i = 0; i < f.size(); i++) f[i] = (float)X[i];
-        check(dpf_fit(S.ix, f.data(), n), "dpf_fit");
+        check(st, dpf_fit(st.ix, f.data(), n), "dpf_fit");
     } else {
-        check(dpf_fit(S.ix, X, n), "dpf_fit");
+        check(st, dpf_fit(st.ix, X, n), "dpf_fit");
     }
-    S.n += n;
+    st.n += n;
 }
+void fit_rows(const double *X, int64_t n) { fit_rows(S, X, n); }
 
 }  // namespace
 
-void detail_partitioner(std::vector<double> &pf, std::vector<double> &pb, std::vector<int32_t> &pw)
+void detail_partitioner(std::vector<double> &pf, std::vector<double> &pb, std::vector<int32_t> &pw, bool sparse)
 {
-    pf = S.part_fns; pb = S.part_b; pw = S.part_w;
+    const State &st = sparse ? T : S;
+    pf = st.part_fns; pb = st.part_b; pw = st.part_w;
 }
 
 dpf_index *DensevectorRDFInit::handle() { return S.ix; }
 int64_t DensevectorRDFInit::size() { return S.n; }
 
-void DensevectorRDFInit::initializeRDFHashMap(const Config &conf)
+static void init_index(State &S, const Config &conf)
 {
     if (!LSHServer::lshEngine) throw MclabError("NullPointerException: LSHServer.lshEngine is null");
-    if (!LSHServer::isUseDense)
-        // Hasher.scala:47-51 would cast the DenseVector to SparseVector
-        throw MclabError("ClassCastException: LSHServer.isUseDense must be true for DensevectorRDFInit");
-    clearAndClose();
+    if (S.ix) dpf_destroy(S.ix);
+    S = State();
     const lsh::LSH &engine = *LSHServer::lshEngine;
     const lsh::HashFamilyData &fam = engine.family();
     const int tableNum = conf.getInt("mclab.lsh.tableNum");                  // Dense:52-58
@@ -603,9 +637,9 @@ void DensevectorRDFInit::initializeRDFHashMap(const Config &conf)
     c.device = conf.getIntOr("mclab.gpu.device", 0);
     c.row_begin = 0; c.row_end = -1;
     if (c.chain_length != fam.chainLength) throw MclabError("mclab.lshTable.chainLength differs from the LSH engine's chain length");
-    check(dpf_create(&c, &S.ix), "dpf_create");
+    check(S, dpf_create(&c, &S.ix), "dpf_create");
     std::vector<int32_t> chains(fam.chain_fn.begin(), fam.chain_fn.begin() + (size_t)L * fam.chainLength);
-    check(dpf_set_hash_family(S.ix, fam.fns.data(), fam.b.empty() ? nullptr : fam.b.data(),
+    check(S, dpf_set_hash_family(S.ix, fam.fns.data(), fam.b.empty() ? nullptr : fam.b.data(),
                               fam.w.empty() ? nullptr : fam.w.data(), chains.data()), "dpf_set_hash_family");
     if (partitionBits > 0) {
         // Dense:63-77: every table gets its own LocalitySensitivePartitioner built from the main
@@ -626,17 +660,26 @@ void DensevectorRDFInit::initializeRDFHashMap(const Config &conf)
                 if (pfam.family == DPF_FAMILY_PSTABLE) { pbv.push_back(pfam.b[(size_t)fn]); pw.push_back(pfam.w[(size_t)fn]); }
             }
         }
-        check(dpf_set_partitioner(S.ix, pf.data(), pbv.empty() ? nullptr : pbv.data(), pw.empty() ? nullptr : pw.data()), "dpf_set_partitioner");
+        check(S, dpf_set_partitioner(S.ix, pf.data(), pbv.empty() ? nullptr : pbv.data(), pw.empty() ? nullptr : pw.data()), "dpf_set_partitioner");
         S.part_fns = pf; S.part_b = pbv; S.part_w = pw;
     }
     if (c.type_of_index == DPF_INDEX_SAMPLING) {
         int32_t si[32];
         lsh::scala_shuffle_0_31(88387, si);
-        check(dpf_set_sampling_index(S.ix, si), "dpf_set_sampling_index");
+        check(S, dpf_set_sampling_index(S.ix, si), "dpf_set_sampling_index");
     }
     S.createFlag = true;
     S.tableNum = tableNum; S.permutationNum = permutationNum; S.L = L; S.pb = partitionBits; S.dim = fam.dim;
     S.n = 0;
+}
+
+void DensevectorRDFInit::initializeRDFHashMap(const Config &conf)
+{
+    if (!LSHServer::lshEngine) throw MclabError("NullPointerException: LSHServer.lshEngine is null");
+    if (!LSHServer::isUseDense)
+        // Hasher.scala:47-51 would cast the DenseVector to SparseVector
+        throw MclabError("ClassCastException: LSHServer.isUseDense must be true for DensevectorRDFInit");
+    init_index(S, conf);
 }
 
 static std::vector<lsh::vector::DenseVector> fit_file(const std::string &fileName, const Config &conf)
@@ -684,8 +727,15 @@ void DensevectorRDFInit::fitVectors(const std::vector<DenseVector> &vectors, con
     fit_rows(flat.data(), (int64_t)vectors.size());
 }
 
+static void query_csr(State &S, const int32_t *qids, const double *Q, int64_t nq, int steps,
+                      std::vector<int64_t> &offsets, std::vector<int32_t> &ids);
 void DensevectorRDFInit::queryBatchCSR(const int32_t *qids, const double *Q, int64_t nq, int steps,
                                        std::vector<int64_t> &offsets, std::vector<int32_t> &ids)
+{
+    query_csr(S, qids, Q, nq, steps, offsets, ids);
+}
+static void query_csr(State &S, const int32_t *qids, const double *Q, int64_t nq, int steps,
+                      std::vector<int64_t> &offsets, std::vector<int32_t> &ids)
 {
     offsets.assign((size_t)nq + 1, 0);
     ids.clear();
@@ -703,7 +753,7 @@ void DensevectorRDFInit::queryBatchCSR(const int32_t *qids, const double *Q, int
     } else {
         rc = dpf_query_batch(S.ix, qids, Q, nq, steps, offsets.data(), &out);
     }
-    check(rc, "dpf_query_batch");
+    check(S, rc, "dpf_query_batch");
     ids.assign(out, out + offsets[(size_t)nq]);
     dpf_free(out);
 }
@@ -829,6 +879,234 @@ std::pair<std::vector<double>, std::vector<double>> DensevectorRDFInit::getDtAnd
     if (S.ix) {
         ht.assign((size_t)1 << S.pb, 0.0);
         check(dpf_subindex_distribution(S.ix, ht.data()), "dpf_subindex_distribution");
+    }
+    return {dt, ht};
+}
+
+// ---------------------------------------------------------------------------
+// SparsevectorRDFInit (src/main/scala/mclab/deploy/SparsevectorRDFInit.scala): the same tables fed with
+// SparseVectors.  A sparse vector hashes as its dense form does: the sparse x sparse dot product
+// (SimilarityCalculator.scala:9-27) walks the common indices in ascending order and an absent index only
+// leaves out a term a_i * 0, which changes no fp64 partial sum.  So the vectors are densified at this
+// boundary and the dense engine does the rest; what differs is which walk a query takes (below).
+// ---------------------------------------------------------------------------
+using lsh::vector::SparseVector;
+
+static std::vector<double> densify(const SparseVector &v, int dim)
+{
+    if (v.size != dim) throw MclabError("requirement failed: vector1 size: " + std::to_string(dim) + ", vector2 size: " + std::to_string(v.size));
+    if (v.indices.size() != v.values.size())
+        throw MclabError("requirement failed: indices length: " + std::to_string(v.indices.size()) + ", values length: " + std::to_string(v.values.size()));
+    std::vector<double> d((size_t)dim, 0.0);
+    for (size_t i = 0; i < v.indices.size(); i++) {
+        if (v.indices[i] < 0 || v.indices[i] >= dim) throw MclabError("ArrayIndexOutOfBoundsException: " + std::to_string(v.indices[i]));
+        d[(size_t)v.indices[i]] = v.values[i];
+    }
+    return d;
+}
+
+dpf_index *SparsevectorRDFInit::handle() { return T.ix; }
+int64_t SparsevectorRDFInit::size() { return T.n; }
+
+void SparsevectorRDFInit::initializeRDFHashMap(const Config &conf)
+{
+    if (!LSHServer::lshEngine) throw MclabError("NullPointerException: LSHServer.lshEngine is null");
+    if (LSHServer::isUseDense)
+        // Hasher.scala:47-51 would cast the SparseVector to DenseVector
+        throw MclabError("ClassCastException: LSHServer.isUseDense must be false for SparsevectorRDFInit");
+    init_index(T, conf);
+}
+
+static void sparse_fit(const std::vector<SparseVector> &vectors)
+{
+    std::vector<double> flat;
+    flat.reserve(vectors.size() * (size_t)T.dim);
+    for (const SparseVector &v : vectors) { std::vector<double> d = densify(v, T.dim); flat.insert(flat.end(), d.begin(), d.end()); }
+    fit_rows(T, flat.data(), (int64_t)vectors.size());
+    T.rows.insert(T.rows.end(), flat.begin(), flat.end());
+}
+
+static std::vector<std::vector<double>> sparse_fit_file(const std::string &fileName, const Config &conf)
+{
+    if (!LSHServer::lshEngine) LSHServer::lshEngine = std::make_shared<lsh::LSH>(conf);      // Sparse:125-127,159
+    SparsevectorRDFInit::initializeRDFHashMap(conf);
+    std::cout << "Finish initialize the RDF." << std::endl;
+    std::ifstream f(lsh::LSH::resolveResource(fileName));
+    if (!f) throw MclabError("NullPointerException: resource " + fileName + " not found");
+    std::vector<SparseVector> all;
+    std::vector<std::vector<double>> values;
+    std::string line;
+    while (std::getline(f, line)) {
+        if (line.empty()) continue;
+        lsh::vector::SparseTuple t = lsh::vector::Vectors::fromPythonString(line);       // Sparse:134,175
+        SparseVector v;
+        v.vectorId = t.id; v.size = t.size; v.indices = t.indices; v.values = t.values;
+        values.push_back(t.values);                      // Sparse:136,179: the stored values, not the dense form
+        all.push_back(std::move(v));
+        if (all.size() % 10000 == 0) std::cout << all.size() << " objects loaded" << std::endl;
+    }
+    sparse_fit(all);
+    std::cout << "finish load, totally " << all.size() << " objects." << std::endl;
+    return values;
+}
+
+std::vector<std::vector<double>> SparsevectorRDFInit::newFastFit(const std::string &fileName, const Config &conf)
+{
+    return sparse_fit_file(fileName, conf);
+}
+
+std::vector<std::vector<double>> SparsevectorRDFInit::newMultiThreadFit(const std::string &fileName, const Config &conf)
+{
+    (void)conf.getInt("mclab.insertThreadNum");                                          // Sparse:160
+    return sparse_fit_file(fileName, conf);
+}
+
+void SparsevectorRDFInit::fitVectors(const std::vector<SparseVector> &vectors, const Config &conf)
+{
+    if (!LSHServer::lshEngine) LSHServer::lshEngine = std::make_shared<lsh::LSH>(conf);
+    initializeRDFHashMap(conf);
+    sparse_fit(vectors);
+}
+
+// Sparse:324-350 -> QueryTask.query (Sparse:402-420) -> RandomDrawTreeMap.getSimilarWithStepWise(key, steps)
+// (RandomDrawTreeMap.java:630-675): the key's stored vector is hashed and only that hash is looked up, in every
+// sub-index within `steps`.  A key the index does not hold makes the reference's hash() fail on a null vector; the
+// worker catches the NullPointerException, prints "need to fit the data first" and leaves that query's set empty.
+std::vector<std::set<int>> SparsevectorRDFInit::NewMultiThreadQueryBatch(const std::vector<int> &queryArray, int steps,
+                                                                         int queryThreadNum)
+{
+    (void)queryThreadNum;
+    const size_t nq = queryArray.size();
+    std::vector<std::set<int>> out(nq);
+    if (!T.ix || T.n == 0) { for (size_t i = 0; i < nq; i++) std::cout << "need to fit the data first" << std::endl; return out; }
+    std::vector<int32_t> keys;
+    std::vector<size_t> where;
+    std::vector<double> flat;
+    for (size_t i = 0; i < nq; i++) {
+        const int key = queryArray[i];
+        if (key < 0 || key >= T.n) { std::cout << "need to fit the data first" << std::endl; continue; }
+        keys.push_back(key);
+        where.push_back(i);
+        flat.insert(flat.end(), T.rows.begin() + (size_t)key * T.dim, T.rows.begin() + (size_t)(key + 1) * T.dim);
+    }
+    if (keys.empty()) return out;
+    std::vector<int64_t> off;
+    std::vector<int32_t> ids;
+    check(T, dpf_set_probe_mode(T.ix, DPF_PROBE_OWN), "dpf_set_probe_mode");
+    try { query_csr(T, keys.data(), flat.data(), (int64_t)keys.size(), steps, off, ids); }
+    catch (...) { dpf_set_probe_mode(T.ix, DPF_PROBE_FLIPS); throw; }
+    check(T, dpf_set_probe_mode(T.ix, DPF_PROBE_FLIPS), "dpf_set_probe_mode");
+    for (size_t j = 0; j < keys.size(); j++) out[where[j]].insert(ids.begin() + off[j], ids.begin() + off[j + 1]);
+    return out;
+}
+
+// Sparse:360-387: the query vectors are put into the index first (ids size, size+1, ...), then looked up by key
+std::vector<std::set<int>> SparsevectorRDFInit::NewMultiThreadQueryBatch(const std::vector<SparseVector> &vectors, int steps,
+                                                                         int queryThreadNum)
+{
+    if (!T.ix) throw MclabError("NullPointerException: index not initialised");
+    std::vector<int> queryArray(vectors.size());
+    for (size_t i = 0; i < vectors.size(); i++) queryArray[i] = (int)(T.n + (int64_t)i);
+    sparse_fit(vectors);
+    std::cout << "finish load, dataTable totally has " << T.n << " objects." << std::endl;
+    return NewMultiThreadQueryBatch(queryArray, steps, queryThreadNum);
+}
+
+// Sparse:529-555 -> QueryTaskNew (Sparse:569-586): getSimilarWithStepWiseFaster with the given vectors, as the dense object
+std::vector<std::set<int>> SparsevectorRDFInit::query(const std::vector<int> &queryKeyArray, const std::vector<SparseVector> &vectors,
+                                                      int steps, int queryThreadNum)
+{
+    (void)queryThreadNum;
+    if (vectors.size() < queryKeyArray.size()) throw MclabError("ArrayIndexOutOfBoundsException: " + std::to_string(vectors.size()));
+    const size_t nq = queryKeyArray.size();
+    std::vector<int64_t> off;
+    std::vector<int32_t> ids;
+    if (!T.ix || T.n == 0) { query_csr(T, nullptr, nullptr, (int64_t)nq, steps, off, ids); return to_sets(off, ids); }
+    std::vector<double> flat;
+    for (size_t i = 0; i < nq; i++) { std::vector<double> d = densify(vectors[i], T.dim); flat.insert(flat.end(), d.begin(), d.end()); }
+    std::vector<int32_t> q(queryKeyArray.begin(), queryKeyArray.end());
+    query_csr(T, q.data(), flat.data(), (int64_t)nq, steps, off, ids);
+    return to_sets(off, ids);
+}
+
+std::set<int> SparsevectorRDFInit::querySingleKey(int queryKey, const SparseVector &v, int steps, int L)     // Sparse:278
+{
+    if (L >= 0 && L != T.L) throw MclabError("querySingleKey over a prefix of the tables (L != tableNum*permutationNum) is not offered on the device");
+    return query(std::vector<int>{queryKey}, std::vector<SparseVector>{v}, steps, 1)[0];
+}
+
+std::vector<std::set<int>> SparsevectorRDFInit::queryBatch(const std::vector<int> &queryArray, const std::vector<SparseVector> &vectors,
+                                                           int steps, int L)                                   // Sparse:300
+{
+    if (L >= 0 && L != T.L) throw MclabError("queryBatch over a prefix of the tables (L != tableNum*permutationNum) is not offered on the device");
+    return query(queryArray, vectors, steps, 1);
+}
+
+// Sparse:458-502: the queries are the first groundTruth.length rows of allDenseVectors, looked up with
+// getSimilarWithStepWiseFaster (Sparse:468 -> query); top-k by descending inner product; the third value is the
+// time the lookup took, in milliseconds
+std::tuple<std::vector<std::vector<int>>, double, long> SparsevectorRDFInit::topKAndPrecisionScore(
+    const std::vector<std::vector<double>> &allDenseVectors, const std::vector<std::set<int>> &groundTruth, const Config &conf, int steps)
+{
+    (void)conf.getInt("mclab.queryThreadNum");
+    const int topK = conf.getInt("mclab.lsh.topK");
+    const size_t nq = groundTruth.size();
+    if (allDenseVectors.size() < nq) throw MclabError("ArrayIndexOutOfBoundsException: " + std::to_string(allDenseVectors.size()));
+    std::vector<std::vector<int>> allTopK;
+    if (!T.ix || T.n == 0) { for (size_t i = 0; i < nq; i++) std::cout << "need to fit the data first" << std::endl; return std::make_tuple(allTopK, 0.0, 0L); }
+    if (topK < 1 || topK > 64) throw MclabError("mclab.lsh.topK must be in [1, 64]");
+    std::vector<double> flat(nq * (size_t)T.dim);
+    for (size_t i = 0; i < nq; i++) {
+        if ((int)allDenseVectors[i].size() != T.dim) throw MclabError("requirement failed: vector1 size: " + std::to_string(T.dim) + ", vector2 size: " + std::to_string(allDenseVectors[i].size()));
+        std::copy(allDenseVectors[i].begin(), allDenseVectors[i].end(), flat.begin() + i * (size_t)T.dim);
+    }
+    std::vector<int32_t> qids(nq), ids(nq * (size_t)topK);
+    for (size_t i = 0; i < nq; i++) qids[i] = (int32_t)i;
+    std::vector<double> scores(nq * (size_t)topK);
+    const auto t0 = std::chrono::steady_clock::now();
+    int rc;
+    if (T.store_f32) {
+        std::vector<float> f(flat.begin(), flat.end());
+        rc = dpf_query_topk(T.ix, qids.data(), f.data(), (int64_t)nq, steps, topK, ids.data(), scores.data());
+    } else {
+        rc = dpf_query_topk(T.ix, qids.data(), flat.data(), (int64_t)nq, steps, topK, ids.data(), scores.data());
+    }
+    const long ms = (long)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+    check(T, rc, "dpf_query_topk");
+    double averageScore = 0.0;
+    for (size_t i = 0; i < nq; i++) {
+        std::vector<int> one;
+        double score = 0.0;
+        for (int wv = 0; wv < topK; wv++) {
+            const int id = ids[i * (size_t)topK + wv];
+            if (id < 0) break;
+            one.push_back(id);
+            if (groundTruth[i].count(id)) score += 1;
+        }
+        if (one.empty()) continue;
+        allTopK.push_back(std::move(one));
+        averageScore += score / (double)nq;
+    }
+    return std::make_tuple(allTopK, averageScore / topK, ms);
+}
+
+std::vector<std::set<int>> SparsevectorRDFInit::getTopKGroundTruth(const std::string &filename, int K)
+{
+    return DensevectorRDFInit::getTopKGroundTruth(filename, K);                           // Sparse:427-434, same body
+}
+
+void SparsevectorRDFInit::clearAndClose()
+{
+    if (T.ix) dpf_destroy(T.ix);
+    T = State();
+}
+
+std::pair<std::vector<double>, std::vector<double>> SparsevectorRDFInit::getDtAndHtNumDistribution()
+{
+    std::vector<double> dt{(double)T.n}, ht;
+    if (T.ix) {
+        ht.assign((size_t)1 << T.pb, 0.0);
+        check(T, dpf_subindex_distribution(T.ix, ht.data()), "dpf_subindex_distribution");
     }
     return {dt, ht};
 }
@@ -1007,7 +1285,19 @@ int mclab_Dense_copy_partitioner(double *part_fns, double *part_b, int32_t *part
     return guarded([&] {
         std::vector<double> pf, pb;
         std::vector<int32_t> pw;
-        mclab::deploy::detail_partitioner(pf, pb, pw);
+        mclab::deploy::detail_partitioner(pf, pb, pw, false);
+        std::copy(pf.begin(), pf.end(), part_fns);
+        if (part_b) std::copy(pb.begin(), pb.end(), part_b);
+        if (part_w) std::copy(pw.begin(), pw.end(), part_w);
+    });
+}
+
+int mclab_Sparse_copy_partitioner(double *part_fns, double *part_b, int32_t *part_w)
+{
+    return guarded([&] {
+        std::vector<double> pf, pb;
+        std::vector<int32_t> pw;
+        mclab::deploy::detail_partitioner(pf, pb, pw, true);
         std::copy(pf.begin(), pf.end(), part_fns);
         if (part_b) std::copy(pb.begin(), pb.end(), part_b);
         if (part_w) std::copy(pw.begin(), pw.end(), part_w);
@@ -1016,6 +1306,102 @@ int mclab_Dense_copy_partitioner(double *part_fns, double *part_b, int32_t *part
 
 void *mclab_Dense_handle(void) { return DensevectorRDFInit::handle(); }
 int64_t mclab_Dense_size(void) { return DensevectorRDFInit::size(); }
+
+// ---- SparsevectorRDFInit: vectors cross this boundary as CSR (row offsets, indices, values) ----
+static std::vector<mclab::lsh::vector::SparseVector> csr_vectors(const int64_t *row_off, const int32_t *indices, const double *values,
+                                                                 int64_t n, int dim)
+{
+    std::vector<mclab::lsh::vector::SparseVector> v((size_t)n);
+    for (int64_t i = 0; i < n; i++) {
+        v[(size_t)i].vectorId = (int)i; v[(size_t)i].size = dim;
+        v[(size_t)i].indices.assign(indices + row_off[i], indices + row_off[i + 1]);
+        v[(size_t)i].values.assign(values + row_off[i], values + row_off[i + 1]);
+    }
+    return v;
+}
+static void sets_out(const std::vector<std::set<int>> &sets, int64_t *offsets, int32_t **ids)
+{
+    std::vector<int32_t> out;
+    offsets[0] = 0;
+    for (size_t q = 0; q < sets.size(); q++) { out.insert(out.end(), sets[q].begin(), sets[q].end()); offsets[q + 1] = (int64_t)out.size(); }
+    *ids = copy_out(out);
+}
+
+int mclab_Sparse_fit_file(const char *fileName, const char *conf_text, int multiThread, int64_t *n)
+{
+    using mclab::deploy::SparsevectorRDFInit;
+    return guarded([&] {
+        Config conf = Config::parseString(conf_text);
+        auto all = multiThread ? SparsevectorRDFInit::newMultiThreadFit(fileName, conf) : SparsevectorRDFInit::newFastFit(fileName, conf);
+        *n = (int64_t)all.size();
+    });
+}
+
+int mclab_Sparse_fit_csr(const int64_t *row_off, const int32_t *indices, const double *values, int64_t n, int dim, const char *conf_text)
+{
+    return guarded([&] { mclab::deploy::SparsevectorRDFInit::fitVectors(csr_vectors(row_off, indices, values, n, dim), Config::parseString(conf_text)); });
+}
+
+int mclab_Sparse_NewMultiThreadQueryBatch_keys(const int32_t *keys, int64_t nq, int steps, int queryThreadNum, int64_t *offsets, int32_t **ids)
+{
+    return guarded([&] {
+        std::vector<int> q(keys, keys + nq);
+        sets_out(mclab::deploy::SparsevectorRDFInit::NewMultiThreadQueryBatch(q, steps, queryThreadNum), offsets, ids);
+    });
+}
+
+int mclab_Sparse_NewMultiThreadQueryBatch_insert(const int64_t *row_off, const int32_t *indices, const double *values, int64_t nq, int dim,
+                                                 int steps, int queryThreadNum, int64_t *offsets, int32_t **ids)
+{
+    return guarded([&] {
+        sets_out(mclab::deploy::SparsevectorRDFInit::NewMultiThreadQueryBatch(csr_vectors(row_off, indices, values, nq, dim), steps, queryThreadNum),
+                 offsets, ids);
+    });
+}
+
+int mclab_Sparse_query(const int32_t *keys, const int64_t *row_off, const int32_t *indices, const double *values, int64_t nq, int dim,
+                       int steps, int queryThreadNum, int64_t *offsets, int32_t **ids)
+{
+    return guarded([&] {
+        std::vector<int> q(keys, keys + nq);
+        sets_out(mclab::deploy::SparsevectorRDFInit::query(q, csr_vectors(row_off, indices, values, nq, dim), steps, queryThreadNum), offsets, ids);
+    });
+}
+
+int mclab_Sparse_topKAndPrecisionScore(const double *vectors, int64_t nq, int dim, const int64_t *gt_off, const int32_t *gt_ids,
+                                       const char *conf_text, int steps, int topK, int32_t *topk_ids, int64_t *rows, double *score,
+                                       int64_t *elapsed_ms)
+{
+    return guarded([&] {
+        std::vector<std::vector<double>> v;
+        std::vector<std::set<int>> gt((size_t)nq);
+        for (int64_t i = 0; i < nq; i++) {
+            v.emplace_back(vectors + i * dim, vectors + (i + 1) * dim);
+            gt[(size_t)i].insert(gt_ids + gt_off[i], gt_ids + gt_off[i + 1]);
+        }
+        auto r = mclab::deploy::SparsevectorRDFInit::topKAndPrecisionScore(v, gt, Config::parseString(conf_text), steps);
+        const auto &top = std::get<0>(r);
+        *rows = (int64_t)top.size();
+        for (size_t i = 0; i < top.size(); i++)
+            for (int j = 0; j < topK; j++) topk_ids[i * (size_t)topK + j] = j < (int)top[i].size() ? top[i][(size_t)j] : -1;
+        *score = std::get<1>(r);
+        *elapsed_ms = (int64_t)std::get<2>(r);
+    });
+}
+
+int mclab_Sparse_clearAndClose(void) { return guarded([] { mclab::deploy::SparsevectorRDFInit::clearAndClose(); }); }
+int64_t mclab_Sparse_size(void) { return mclab::deploy::SparsevectorRDFInit::size(); }
+void *mclab_Sparse_handle(void) { return mclab::deploy::SparsevectorRDFInit::handle(); }
+
+int mclab_Vectors_fromPythonString(const char *line, int32_t *id, int32_t *size, int32_t *indices, double *values, int cap, int *nnz)
+{
+    return guarded([&] {
+        auto t = lsh::vector::Vectors::fromPythonString(line);
+        *id = t.id; *size = t.size; *nnz = (int)t.values.size();
+        for (int i = 0; i < (int)t.indices.size() && i < cap; i++) indices[i] = t.indices[(size_t)i];
+        for (int i = 0; i < *nnz && i < cap; i++) values[i] = t.values[(size_t)i];
+    });
+}
 
 int mclab_Vectors_parseDense(const char *line, int32_t *id, double *values, int cap, int *n)
 {

@@ -46,6 +46,16 @@ def _L():
     L.mclab_Vectors_parseDense.argtypes = [C.c_char_p, ip, dp, C.c_int, C.POINTER(C.c_int)]
     L.mclab_Vectors_fromString.argtypes = [C.c_char_p, ip, ip, ip, dp, C.c_int, C.POINTER(C.c_int)]
     L.mclab_Vectors_analysisKNN.argtypes = [C.c_char_p, C.c_int, ip]
+    L.mclab_Vectors_fromPythonString.argtypes = [C.c_char_p, ip, ip, ip, dp, C.c_int, C.POINTER(C.c_int)]
+    L.mclab_Sparse_fit_file.argtypes = [C.c_char_p, C.c_char_p, C.c_int, i64p]
+    L.mclab_Sparse_fit_csr.argtypes = [i64p, ip, dp, C.c_int64, C.c_int, C.c_char_p]
+    L.mclab_Sparse_NewMultiThreadQueryBatch_keys.argtypes = [ip, C.c_int64, C.c_int, C.c_int, i64p, C.POINTER(ip)]
+    L.mclab_Sparse_NewMultiThreadQueryBatch_insert.argtypes = [i64p, ip, dp, C.c_int64, C.c_int, C.c_int, C.c_int, i64p, C.POINTER(ip)]
+    L.mclab_Sparse_query.argtypes = [ip, i64p, ip, dp, C.c_int64, C.c_int, C.c_int, C.c_int, i64p, C.POINTER(ip)]
+    L.mclab_Sparse_topKAndPrecisionScore.argtypes = [dp, C.c_int64, C.c_int, i64p, ip, C.c_char_p, C.c_int, C.c_int, ip, i64p, dp, i64p]
+    L.mclab_Sparse_copy_partitioner.argtypes = [dp, dp, ip]
+    L.mclab_Sparse_handle.restype = C.c_void_p
+    L.mclab_Sparse_size.restype = C.c_int64
     L._mclab_ready = True
     return L
 
@@ -133,7 +143,39 @@ class DenseVector:
         return self.values
 
 
+class SparseVector:
+    """mclab.lsh.vector.SparseVector (Vector.scala:374-378): (vectorId, size, indices, values)."""
+
+    def __init__(self, vectorId, size, indices, values):
+        self.vectorId, self.size = int(vectorId), int(size)
+        self.indices = np.ascontiguousarray(indices, dtype=np.int32)
+        self.values = np.ascontiguousarray(values, dtype=np.float64)
+        if self.indices.shape != self.values.shape:
+            raise MclabError("requirement failed: indices length: %d, values length: %d" % (self.indices.size, self.values.size))
+
+    def toArray(self):
+        d = np.zeros(self.size, dtype=np.float64)
+        d[self.indices] = self.values
+        return d
+
+
 class Vectors:
+    @staticmethod
+    def sparse(vectorId, size, indices, values):
+        """Vectors.sparse (Vector.scala:86-88)."""
+        return SparseVector(vectorId, size, indices, values)
+
+    @staticmethod
+    def fromPythonString(line):
+        """Vector.scala:194-208: "[1, 3, [1, 2, 3], [1.0, 2.0, 3.0]]" -> (id, size, indices, values)."""
+        cap = line.count(",") + 2
+        idx = np.empty(cap, dtype=np.int32)
+        vals = np.empty(cap, dtype=np.float64)
+        vid, size, nnz = C.c_int32(), C.c_int32(), C.c_int()
+        _check(_L().mclab_Vectors_fromPythonString(line.encode(), C.byref(vid), C.byref(size), _lib._ip(idx), _lib._dp(vals),
+                                                   cap, C.byref(nnz)))
+        return vid.value, size.value, idx[:nnz.value].copy(), vals[:nnz.value].copy()
+
     @staticmethod
     def parseDense(line):
         """Vector.scala:215-219 -> (vectorId, values)."""
@@ -359,3 +401,130 @@ class _DensevectorRDFInit:
 
 
 DensevectorRDFInit = _DensevectorRDFInit()
+
+
+
+def _csr_of(vectors):
+    """list of SparseVector -> (row offsets, indices, values, dim) for the C veneer."""
+    dim = vectors[0].size if vectors else 0
+    off = np.zeros(len(vectors) + 1, dtype=np.int64)
+    for i, v in enumerate(vectors):
+        if v.size != dim:
+            raise MclabError("requirement failed: vector1 size: %d, vector2 size: %d" % (dim, v.size))
+        off[i + 1] = off[i] + v.indices.shape[0]
+    idx = np.concatenate([v.indices for v in vectors]).astype(np.int32) if vectors else np.zeros(1, dtype=np.int32)
+    val = np.concatenate([v.values for v in vectors]).astype(np.float64) if vectors else np.zeros(1)
+    if idx.size == 0:
+        idx, val = np.zeros(1, dtype=np.int32), np.zeros(1)
+    return off, np.ascontiguousarray(idx), np.ascontiguousarray(val), dim
+
+
+class _SparsevectorRDFInit:
+    """mclab.deploy.SparsevectorRDFInit (SparsevectorRDFInit.scala:20-593): the same tables fed with SparseVectors.
+    LSHServer.isUseDense must be False.  A sparse vector hashes exactly as its dense form does, so the vectors are
+    densified at the boundary; what differs from the dense object is the keyed batch query, which looks up the hash of
+    the key's stored vector only (RandomDrawTreeMap.getSimilarWithStepWise, RandomDrawTreeMap.java:630-675)."""
+
+    def _ensure_engine(self, conf):
+        if LSHServer.lshEngine is None:
+            LSHServer.lshEngine = LSH(conf)
+
+    def newMultiThreadFit(self, fileName, conf):
+        """Sparse:158-206 -> number of vectors indexed (lines in the Vectors.fromPythonString format)."""
+        self._ensure_engine(conf)
+        n = C.c_int64()
+        _check(_L().mclab_Sparse_fit_file(str(fileName).encode(), conf.text().encode(), 1, C.byref(n)))
+        return n.value
+
+    def newFastFit(self, fileName, conf):
+        """Sparse:124-151."""
+        self._ensure_engine(conf)
+        n = C.c_int64()
+        _check(_L().mclab_Sparse_fit_file(str(fileName).encode(), conf.text().encode(), 0, C.byref(n)))
+        return n.value
+
+    def fitVectors(self, vectors, conf):
+        """Same fit from a list of SparseVector (ids = positions)."""
+        self._ensure_engine(conf)
+        off, idx, val, dim = _csr_of(vectors)
+        _check(_L().mclab_Sparse_fit_csr(off.ctypes.data_as(C.POINTER(C.c_int64)), _lib._ip(idx), _lib._dp(val), len(vectors), dim,
+                                         conf.text().encode()))
+
+    @staticmethod
+    def _sets(call, nq):
+        pids = C.POINTER(C.c_int32)()
+        off = np.zeros(nq + 1, dtype=np.int64)
+        _check(call(off.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(pids)))
+        total = int(off[-1])
+        ids = np.ctypeslib.as_array(pids, shape=(max(total, 1),))[:total].copy()
+        _lib.lib().dpf_free(pids)
+        return _csr_to_sets(off, ids)
+
+    def NewMultiThreadQueryBatch(self, queryArray, steps=0, queryThreadNum=5):
+        """By key (Sparse:324-350): list of int ids -> the keyed walk; a list of SparseVector (Sparse:360-387) is first
+        appended to the index and then looked up under its new ids."""
+        L = _L()
+        if len(queryArray) and isinstance(queryArray[0], SparseVector):
+            off, idx, val, dim = _csr_of(list(queryArray))
+            return self._sets(lambda o, p: L.mclab_Sparse_NewMultiThreadQueryBatch_insert(
+                off.ctypes.data_as(C.POINTER(C.c_int64)), _lib._ip(idx), _lib._dp(val), len(queryArray), dim, steps, queryThreadNum, o, p),
+                len(queryArray))
+        keys = np.ascontiguousarray(queryArray, dtype=np.int32)
+        return self._sets(lambda o, p: L.mclab_Sparse_NewMultiThreadQueryBatch_keys(_lib._ip(keys), keys.shape[0], steps, queryThreadNum, o, p),
+                          keys.shape[0])
+
+    def query(self, queryKeyArray, querySVArray, steps=0, queryThreadNum=10):
+        """Sparse:529-555: getSimilarWithStepWiseFaster with the given vectors."""
+        keys = np.ascontiguousarray(queryKeyArray, dtype=np.int32)
+        off, idx, val, dim = _csr_of(list(querySVArray)[:keys.shape[0]])
+        return self._sets(lambda o, p: _L().mclab_Sparse_query(_lib._ip(keys), off.ctypes.data_as(C.POINTER(C.c_int64)), _lib._ip(idx),
+                                                               _lib._dp(val), keys.shape[0], dim, steps, queryThreadNum, o, p), keys.shape[0])
+
+    def queryBatch(self, queryArray, sparseVectorArray, steps, L=None):
+        """Sparse:300-306."""
+        return self.query(queryArray, sparseVectorArray, steps, 1)
+
+    def querySingleKey(self, queryKey, sparseVector, steps=0, L=None):
+        """Sparse:278-292."""
+        return self.query([queryKey], [sparseVector], steps, 1)[0]
+
+    def topKAndPrecisionScore(self, allDenseVectors, groundTruth, conf, steps=0):
+        """Sparse:458-502 -> (list of top-K id lists, recall@K, milliseconds the lookup took)."""
+        V = np.ascontiguousarray(np.asarray(allDenseVectors, dtype=np.float64))
+        nq = len(groundTruth)
+        topK = conf.getInt("mclab.lsh.topK")
+        off = np.zeros(nq + 1, dtype=np.int64)
+        flat = []
+        for i, g in enumerate(groundTruth):
+            flat.extend(sorted(g))
+            off[i + 1] = len(flat)
+        gt = np.asarray(flat, dtype=np.int32) if flat else np.zeros(1, dtype=np.int32)
+        out = np.empty((max(nq, 1), topK), dtype=np.int32)
+        rows, score, ms = C.c_int64(), C.c_double(), C.c_int64()
+        Vq = np.ascontiguousarray(V[:nq])
+        _check(_L().mclab_Sparse_topKAndPrecisionScore(_lib._dp(Vq), nq, V.shape[1], off.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                       _lib._ip(gt), conf.text().encode(), steps, topK, _lib._ip(out),
+                                                       C.byref(rows), C.byref(score), C.byref(ms)))
+        return [[int(x) for x in r if x >= 0] for r in out[:rows.value]], score.value, ms.value
+
+    def getTopKGroundTruth(self, filename, K):
+        """Sparse:427-434 (the dense object's reader)."""
+        return DensevectorRDFInit.getTopKGroundTruth(filename, K)
+
+    def partitioner(self, L, pb):
+        """The partitioner functions initializeRDFHashMap generated: (part_fns, part_b, part_w)."""
+        pf = np.empty((L, pb, 32))
+        pbv = np.empty((L, pb))
+        pw = np.empty((L, pb), dtype=np.int32)
+        _check(_L().mclab_Sparse_copy_partitioner(_lib._dp(pf), _lib._dp(pbv), _lib._ip(pw)))
+        return pf, pbv, pw
+
+    def size(self):
+        return int(_L().mclab_Sparse_size())
+
+    def clearAndClose(self):
+        """Sparse:440-445."""
+        _check(_L().mclab_Sparse_clearAndClose())
+
+
+SparsevectorRDFInit = _SparsevectorRDFInit()

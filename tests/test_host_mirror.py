@@ -270,3 +270,102 @@ def test_query_before_fit_and_wrong_switch():
     with pytest.raises(MclabError) as ei:
         DensevectorRDFInit.fitVectors(np.zeros((4, 100)), pc)
     assert "IndexOutOfBounds" in str(ei.value)
+
+
+# ------------------------------------------------------------------ SparsevectorRDFInit
+
+def test_vectors_fromPythonString():
+    # Vector.scala:189-208: "[1, 3, [1, 2, 3], [1.0, 2.0, 3.0]]", spaces anywhere
+    vid, size, idx, vals = Vectors.fromPythonString("[1, 3, [1, 2, 3], [1.0, 2.0, 3.0]]")
+    assert (vid, size, idx.tolist(), vals.tolist()) == (1, 3, [1, 2, 3], [1.0, 2.0, 3.0])
+    vid, size, idx, vals = Vectors.fromPythonString("[7,100,[0,99],[ -0.5 , 2e-3 ]]")
+    assert (vid, size, idx.tolist(), vals.tolist()) == (7, 100, [0, 99], [-0.5, 0.002])
+    vid, size, idx, vals = Vectors.fromPythonString("[2, 5, [], []]")
+    assert (vid, size, idx.size, vals.size) == (2, 5, 0, 0)
+    with pytest.raises(MclabError):
+        Vectors.fromPythonString("[1, 3, [1, 2, 3]]")
+
+
+def _sparse_rows(X, rng, keep=0.6):
+    """Rows of X with about `keep` of the entries kept, as SparseVectors (the dropped entries are zeros)."""
+    from similaritysearchbyrdf_amd.host import SparseVector
+    out, dense = [], np.zeros_like(X)
+    for i, x in enumerate(X):
+        idx = np.flatnonzero(rng.random(x.shape[0]) < keep)
+        out.append(SparseVector(i, x.shape[0], idx, x[idx]))
+        dense[i, idx] = x[idx]
+    return out, dense
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,perm", [("angle", 2), ("pStable", 1)])
+def test_sparse_object_flow_matches_oracle(tmp_path, name, perm):
+    # SparsevectorRDFInit: fit from a file of python-style sparse lines; the keyed batch query walks the hash of the
+    # key's own vector only (RandomDrawTreeMap.java:630-675 via SparsevectorRDFInit.scala:407), query() with vectors
+    # walks the bit flips (RandomDrawTreeMap.java:742-797); both against the oracle fitted on the dense forms
+    from similaritysearchbyrdf_amd.host import SparsevectorRDFInit
+    rng = np.random.default_rng(11)
+    centres = rng.normal(size=(12, 100))
+    X = centres[rng.integers(0, 12, size=2500)] + 0.3 * rng.normal(size=(2500, 100))
+    rows, D = _sparse_rows(X, rng)
+    path = tmp_path / "vectors.SparseVector.txt"
+    with open(path, "w") as f:
+        for i, v in enumerate(rows):
+            f.write("[%d, %d, [%s], [%s]]\n" % (2500 - i, v.size, ", ".join(str(int(j)) for j in v.indices),
+                                                 ", ".join(repr(float(x)) for x in v.values)))
+    c = conf(mclab__lsh__name=name, mclab__lsh__permutationNum=perm, mclab__lsh__tableNum=3,
+             mclab__lshTable__bufferOverflow=30, mclab__lsh__family__pstable__w=2)
+    LSHServer.lshEngine = None
+    LSHServer.isUseDense = False
+    LSHServer.lshEngine = LSH(c)
+    n = SparsevectorRDFInit.newMultiThreadFit(str(path), c)
+    assert n == 2500 and SparsevectorRDFInit.size() == 2500
+    from oracle import oracle as O
+    fam = LSHServer.lshEngine.family()
+    L = 3 * perm
+    pf, pbv, pw = SparsevectorRDFInit.partitioner(L, 3)
+    p = dict(family=fam["family"], fns=fam["fns"], b=fam["b"], w=fam["w"], chain_fn=fam["chain_fn"][:L], part_fns=pf,
+             partition_bits=3, bucket_overflow=30)
+    if fam["family"] == "pStable":
+        p.update(part_b=pbv, part_w=pw)
+    orc = O.OracleIndex(p)
+    orc.fit(D)
+    keys = [0, 5, 127, 128, 700, 2499]
+    for steps in (0, 1, 3):
+        orc.set_probe_own(True)
+        off, ids = orc.query_batch(keys, D[keys], steps=steps)
+        got = SparsevectorRDFInit.NewMultiThreadQueryBatch(keys, steps)
+        assert got == [set(ids[off[i]:off[i + 1]].tolist()) for i in range(len(keys))]
+        orc.set_probe_own(False)
+        off, ids = orc.query_batch(keys, D[keys], steps=steps)
+        got = SparsevectorRDFInit.query(keys, [rows[k] for k in keys], steps)
+        assert got == [set(ids[off[i]:off[i + 1]].tolist()) for i in range(len(keys))]
+    assert SparsevectorRDFInit.querySingleKey(700, rows[700], 3) == got[4]
+    # a key the index does not hold: the reference's worker prints "need to fit the data first" and leaves the set empty
+    assert SparsevectorRDFInit.NewMultiThreadQueryBatch([999999], 1) == [set()]
+    # the insert-then-query overload (SparsevectorRDFInit.scala:360-387): new ids 2500.., looked up by key
+    new_rows, newD = _sparse_rows(X[5:7] + 1e-3, rng)
+    got = SparsevectorRDFInit.NewMultiThreadQueryBatch(new_rows, 1)
+    orc.fit(newD)
+    orc.set_probe_own(True)
+    off, ids = orc.query_batch([2500, 2501], newD, steps=1)
+    assert got == [set(ids[off[i]:off[i + 1]].tolist()) for i in range(2)]
+    # top-k + recall through query() (SparsevectorRDFInit.scala:458-502)
+    orc.set_probe_own(False)
+    nq = 100
+    allD = np.vstack([D, newD])
+    gt = np.argsort(-(allD[:nq] @ allD.T), axis=1)[:, :10]
+    groundTruth = [set(r.tolist()) for r in gt]
+    topk, score, ms = SparsevectorRDFInit.topKAndPrecisionScore(allD, groundTruth, c, steps=1)
+    off, ids = orc.query_batch(np.arange(nq), allD[:nq], steps=1)
+    wi, ws = orc.topk(allD[:nq], off, ids, k=10, metric="dot")
+    want = [[int(x) for x in wi[q] if x >= 0] for q in range(nq)]
+    assert topk == [r for r in want if r] and 0.0 < score <= 1.0 and ms >= 0
+    # the dense switch must be off for this object (Hasher.scala:47-51)
+    LSHServer.isUseDense = True
+    with pytest.raises(MclabError) as ei:
+        SparsevectorRDFInit.fitVectors(rows[:4], c)
+    assert "isUseDense" in str(ei.value)
+    LSHServer.isUseDense = False
+    SparsevectorRDFInit.clearAndClose()
+    assert SparsevectorRDFInit.size() == 0
