@@ -121,7 +121,8 @@ private:
     std::string name_, typeOfIndex_;
     HashFamilyData fam_;
     dpf_index *probe_ = nullptr;                                 // lazily created engine used by calculateIndex
-    void ensureProbe();
+    dpf_index *probeRaw_ = nullptr;                              // the same chains without the typeOfIndex transform
+    dpf_index *ensureProbe(bool raw);
 };
 
 }  // namespace lsh

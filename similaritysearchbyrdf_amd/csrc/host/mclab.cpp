@@ -463,16 +463,18 @@ LSH::LSH(const Config &conf) : conf_(conf)
 LSH::~LSH()
 {
     if (probe_) dpf_destroy(probe_);
+    if (probeRaw_) dpf_destroy(probeRaw_);
 }
 
-void LSH::ensureProbe()
+dpf_index *LSH::ensureProbe(bool raw)
 {
-    if (probe_) return;
+    dpf_index *&probe_ = raw ? this->probeRaw_ : this->probe_;
+    if (probe_) return probe_;
     if (fam_.numChains == 0) throw MclabError("IndexOutOfBoundsException: no hash chains (mclab.lsh.name = " + name_ + ")");
     dpf_config c{};
     c.family = fam_.family; c.dim = fam_.dim; c.num_functions = fam_.F(); c.num_tables = fam_.numChains;
     c.chain_length = fam_.chainLength; c.partition_bits = 0; c.bucket_bits = 28; c.dir_node_size = 32;
-    c.bucket_overflow = 500; c.type_of_index = type_of_index_code(typeOfIndex_); c.top_k = 1; c.dtype = DPF_F64;
+    c.bucket_overflow = 500; c.type_of_index = raw ? DPF_INDEX_ORIGINAL : type_of_index_code(typeOfIndex_); c.top_k = 1; c.dtype = DPF_F64;
     c.device = conf_.getIntOr("mclab.gpu.device", 0); c.row_begin = 0; c.row_end = -1;
     c.flags = DPF_FLAG_HASH_ONLY;      // no forest behind this handle: any chain length hashes
     int rc = dpf_create(&c, &probe_);
@@ -485,18 +487,18 @@ void LSH::ensureProbe()
         rc = dpf_set_sampling_index(probe_, si);
     }
     if (rc != DPF_OK) { std::string m = dpf_last_error(probe_); dpf_destroy(probe_); probe_ = nullptr; throw MclabError(m); }
+    return probe_;
 }
 
 std::vector<int> LSH::calculateIndex(const vector::DenseVector &v, int tableId)
 {
     if (v.size() != fam_.dim) throw MclabError("requirement failed: vector1 size: " + std::to_string(fam_.dim) + ", vector2 size: " + std::to_string(v.size()));
     if (tableId >= fam_.numChains) throw MclabError("IndexOutOfBoundsException: " + std::to_string(tableId));
-    ensureProbe();
+    // LSH.scala:136-138: tableId < 0 = every chain's value WITHOUT the typeOfIndex transform
+    dpf_index *probe = ensureProbe(tableId < 0 && typeOfIndex_ != "original");
     std::vector<int32_t> h((size_t)fam_.numChains);
-    if (dpf_hash_batch(probe_, v.values.data(), 1, h.data(), nullptr) != DPF_OK) throw MclabError(dpf_last_error(probe_));
+    if (dpf_hash_batch(probe, v.values.data(), 1, h.data(), nullptr) != DPF_OK) throw MclabError(dpf_last_error(probe));
     if (tableId >= 0) return {h[(size_t)tableId]};
-    // LSH.scala:136-138: every chain's value WITHOUT the typeOfIndex transform
-    if (typeOfIndex_ != "original") throw MclabError("calculateIndex(tableId < 0) with typeOfIndex != original is not offered on the device");
     return std::vector<int>(h.begin(), h.end());
 }
 

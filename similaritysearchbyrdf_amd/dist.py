@@ -57,10 +57,14 @@ def grid_of(world, num_tables):
 
 
 def rows_grid_of(world):
-    """(query groups, row groups) for `world` ranks in "rows" mode: as many row groups as ranks.  Row
-    groups divide the rows a rank's scan reads; query groups divide the per-query work but leave every
-    rank reading all the rows its queries' buckets hold.  (Measured on one MI355X, c3 shape, per-rank batch
-    time: see tools/shard_timing.py.)"""
+    """(query groups, row groups) for `world` ranks in "rows" mode: two row groups, the other factor as query
+    groups (odd world sizes: one query group, `world` row groups).  Row groups divide the rows a rank's scan
+    reads but every rank still hashes and probes all of its queries over all tables; query groups divide that
+    per-query work.  Measured per-rank batch time on one MI355X, c3 shape (tools/shard_timing.py), query groups x
+    row groups: 1x2 2.03 ms, 2x1 2.07; 2x2 1.44, 1x4 1.67; 4x2 1.10, 2x4 1.15, 8x1 1.34, 1x8 1.43.  A base that
+    does not fit two GPUs needs more row groups: pass grid=(qg, rg)."""
+    if world >= 2 and world % 2 == 0:
+        return world // 2, 2
     return 1, world
 
 

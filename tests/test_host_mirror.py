@@ -216,6 +216,33 @@ def test_readme_simple_test_flow(tmp_path, name, perm):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["continueBitsCount", "sampling", "angleNewMethod"])
+def test_calculateIndex_all_tables_skips_the_transform(kind):
+    # LSH.scala:135-138: tableId < 0 returns every chain's value as computed, WITHOUT the typeOfIndex transform
+    # that the single-table branch applies (LSH.scala:152-161)
+    from oracle import oracle as O
+    c = conf(mclab__lsh__typeOfIndex=kind, mclab__lsh__tableNum=3, mclab__lsh__permutationNum=2)
+    LSHServer.lshEngine = None
+    LSHServer.isUseDense = True
+    LSHServer.lshEngine = LSH(c)
+    fam = LSHServer.lshEngine.family()
+    base = dict(family=fam["family"], fns=fam["fns"], b=fam["b"], w=fam["w"], chain_fn=fam["chain_fn"],
+                part_fns=np.zeros((6, 0, 32), dtype=np.int32), partition_bits=0, bucket_overflow=50)
+    if kind == "sampling":        # Sampling.scala: the bit order is scala.util.Random(88387).shuffle(0 until 32)
+        import ctypes as C
+        si = np.empty(32, dtype=np.int32)
+        O.lib().orc_scala_shuffle_0_31(88387, si.ctypes.data_as(C.POINTER(C.c_int32)))
+        base["sampling_index"] = si
+    raw, cooked = O.OracleIndex(dict(base, type_of_index="original")), O.OracleIndex(dict(base, type_of_index=kind))
+    v = np.random.default_rng(5).normal(size=100)
+    every = LSHServer.lshEngine.calculateIndex(DenseVector(0, v), -1)
+    assert list(every) == [raw.hash(t, v) for t in range(6)]
+    one = [LSHServer.lshEngine.calculateIndex(DenseVector(0, v), t)[0] for t in range(6)]
+    assert one == [cooked.hash(t, v) for t in range(6)]
+    assert one != list(every)
+
+
+@pytest.mark.gpu
 def test_topKAndPrecisionScore_matches_oracle(tmp_path):
     rng = np.random.default_rng(8)
     centres = rng.normal(size=(10, 100))
