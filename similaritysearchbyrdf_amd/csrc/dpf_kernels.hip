@@ -1003,7 +1003,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // unit and scored against the queries 16 at a time; buckets probed by very many queries become
 // several units per tile, so no unit is long and a static interleave over the persistent waves
 // balances the chip.
-static constexpr uint32_t UNIT_QUERIES = 128;
+static constexpr uint32_t UNIT_QUERIES = 256;     // (64: c4 +7 %; 128: +1.5 %; 512: as 256; c3 indifferent from 128 on)
 __device__ inline uint32_t units_of_leaf(uint32_t cnt, uint32_t ntl) { return cnt ? ntl * ((cnt + UNIT_QUERIES - 1u) / UNIT_QUERIES) : 0u; }
 
 // The two exclusive scans the batch needs over the buckets, in one set of launches: lq_off[] over the
@@ -1168,9 +1168,10 @@ void launch_tile_maxnorm(uint4 *tiles, int64_t ntiles, const int32_t *ids, const
 }
 
 // Ablation switches of the scan (timing experiments that give wrong answers on purpose) exist only in
-// builds made with -DDPF_ABLATE; the shipped kernel has none.
+// builds made with -DDPF_ABLATE=<bits> (1: loads and products only, 2: every query row from one hot spot,
+// 4: no in-tile tightening); the shipped kernel has none.
 #ifdef DPF_ABLATE
-#define DPF_ABLATION(p, bit) (((p).debug & (bit)) != 0)
+#define DPF_ABLATION(p, bit) (((DPF_ABLATE) & (bit)) != 0)
 #else
 #define DPF_ABLATION(p, bit) false
 #endif
