@@ -18,5 +18,5 @@ while True:
                                              r["Kernel_Name"].split("(")[0].replace("void dpf::", "")[:40]))
     prev = en
     i += 1
-    if i >= len(rows) or "k_hash" in rows[i]["Kernel_Name"]:
-        break
+    if i >= len(rows) or "k_hash" in rows[i]["Kernel_Name"] or "copyBuffer" in rows[i]["Kernel_Name"]:
+        break                     # the next batch, or the caller's copies behind the last one
