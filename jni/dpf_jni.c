@@ -287,3 +287,40 @@ JNIEXPORT jlong JNICALL Java_mclab_gpu_Dpf_load(JNIEnv *env, jclass cls, jstring
     throw_dpf(env, NULL, rc);
     return (jlong)(intptr_t)ix;
 }
+
+/* loadShard(path, device, shard = {table_begin, table_end, subindex_group, subindex_groups}, rowBegin, rowEnd): one rank's
+ * shard of a saved index (the file is memory-mapped; only the shard's rows are copied to the device) */
+JNIEXPORT jlong JNICALL Java_mclab_gpu_Dpf_loadShard(JNIEnv *env, jclass cls, jstring path, jint device, jintArray jshard,
+                                                     jlong rowBegin, jlong rowEnd)
+{
+    (void)cls;
+    if ((*env)->GetArrayLength(env, jshard) != 4) {
+        jclass ex = (*env)->FindClass(env, "java/lang/IllegalArgumentException");
+        if (ex) (*env)->ThrowNew(env, ex, "Dpf.loadShard: shard must hold table_begin, table_end, subindex_group, subindex_groups");
+        return 0;
+    }
+    jint v[4];
+    (*env)->GetIntArrayRegion(env, jshard, 0, 4, v);
+    dpf_config shard;
+    memset(&shard, 0, sizeof shard);
+    shard.table_begin = (int32_t)v[0];
+    shard.table_end = (int32_t)v[1];
+    shard.subindex_group = (int32_t)v[2];
+    shard.subindex_groups = (int32_t)v[3];
+    shard.row_begin = (int64_t)rowBegin;
+    shard.row_end = (int64_t)rowEnd;
+    dpf_index *ix = NULL;
+    const char *p = (*env)->GetStringUTFChars(env, path, NULL);
+    int rc = p ? dpf_load_shard(p, (int32_t)device, &shard, &ix) : DPF_ENOMEM;
+    if (p) (*env)->ReleaseStringUTFChars(env, path, p);
+    throw_dpf(env, NULL, rc);
+    return (jlong)(intptr_t)ix;
+}
+
+/* setOption(h, DPF_OPT_*, value): explicit tuning; no environment variable is read on the query path */
+JNIEXPORT void JNICALL Java_mclab_gpu_Dpf_setOption(JNIEnv *env, jclass cls, jlong h, jint option, jlong value)
+{
+    (void)cls;
+    dpf_index *ix = handle_of(h);
+    throw_dpf(env, ix, dpf_set_option(ix, (int32_t)option, (int64_t)value));
+}

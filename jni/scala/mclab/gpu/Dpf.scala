@@ -21,6 +21,14 @@ object Dpf {
   val ProbeOwn = 1            // RandomDrawTreeMap.getSimilarWithStepWise(key, steps) (RandomDrawTreeMap.java:630-675)
   val F32 = 0
   val F64 = 1
+  // DPF_OPT_* of dpf_set_option
+  val OptEmitCap = 1
+  val OptBucketListCap = 2
+  val OptSyncSizes = 3
+  val OptFirstPassPermille = 4
+  val OptSeedSample = 5
+  val OptShortRerank = 6
+  val OptProjectionMinRows = 7
 
   /** The int32 fields of `dpf_config`, in declaration order (checked against include/dpf.h by tests/test_jni_shim.py). */
   val ConfigIntFields: Array[String] = Array(
@@ -52,4 +60,7 @@ object Dpf {
   @native def setProbeMode(h: Long, mode: Int): Unit
   @native def save(h: Long, path: String): Unit
   @native def load(path: String, device: Int): Long
+  /** shard = Array(table_begin, table_end, subindex_group, subindex_groups); rows [rowBegin, rowEnd), rowEnd < 0 = to the end */
+  @native def loadShard(path: String, device: Int, shard: Array[Int], rowBegin: Long, rowEnd: Long): Long
+  @native def setOption(h: Long, option: Int, value: Long): Unit
 }
