@@ -185,6 +185,7 @@ class ShardedDpf:
             self.index = DpfIndex(params, metric=metric, top_k=top_k, dtype=dtype, device=device, **shard)
         self.tg = self.sg            # (older name)
         self._bufs = None
+        self.always_exchange = False  # True: a single rank also goes through the all-gather and the merge (rehearsals)
 
     def fit(self, X):
         """Every rank sees every row (hashes build the replicated forest); in "rows" mode only the
@@ -202,7 +203,7 @@ class ShardedDpf:
             if (stream or 0) != cur:
                 raise ValueError("ShardedDpf.query_topk: `stream` must be torch's current stream on the index's device "
                                  "(the all-gather and the copies are ordered on that one)")
-        if self.world == 1:
+        if self.world == 1 and not self.always_exchange:
             self.index.query_topk_device(d_qids.data_ptr(), d_Q.data_ptr(), nq, steps, k, out_ids.data_ptr(),
                                          out_scores.data_ptr(), stream)
             return
