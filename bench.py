@@ -196,6 +196,8 @@ def main():
     ap.add_argument("--no-host-to-host", action="store_true")
     ap.add_argument("--in-flight", type=int, default=1, choices=[1, 2],
                     help="2: also measure the throughput with two batches in flight on one GPU (reported as value_two_in_flight)")
+    ap.add_argument("--full-filter", action="store_true",
+                    help="fp16 copies of every dimension (DPF_FLAG_FULL_FILTER) instead of the leading ones: A/B of the truncated filter")
     ap.add_argument("--large-table-rows", type=int, default=4_000_000,
                     help="c3 on one GPU: base rows of the extra roofline run whose fp16 table (256 B per row) is several "
                          "times the Infinity Cache; 0 = skip")
@@ -233,6 +235,8 @@ def main():
     params, X, Q, pick, steps = workload(args.workload, args.n, args.nq, args.dim)
     if args.rerank == "gather":
         params["flags"] = 2          # DPF_FLAG_GATHER_ONLY
+    if args.full_filter:
+        params["flags"] = int(params.get("flags", 0)) | 8          # DPF_FLAG_FULL_FILTER
     if args.search_steps is not None:
         steps = args.search_steps
     n, nq, k = X.shape[0], Q.shape[0], args.k

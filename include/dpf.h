@@ -53,7 +53,12 @@ enum { DPF_FLAG_HASH_ONLY = 1,
        DPF_FLAG_GATHER_ONLY = 2,
 /* DPF_FLAG_HOST_FOREST: derive the forest on the host (sort-based builder, 16 threads) instead of
  * on the device (same arrays; for cross-checking and A/B). */
-       DPF_FLAG_HOST_FOREST = 4 };
+       DPF_FLAG_HOST_FOREST = 4,
+/* DPF_FLAG_FULL_FILTER: the bucket-major scan's fp16 rows keep every dimension.  Without it, l2 handles whose
+ * dimension exceeds a row length the scan has a kernel for by at most 8 (and at most a sixteenth: 100 -> 96,
+ * 136 -> 128, 260 -> 256, ...) scan rows cut there and put the remaining dimensions' share back for the scores that
+ * pass: the same filter in two stages, same results, fewer bytes per scanned row (the flag is for A/B). */
+       DPF_FLAG_FULL_FILTER = 8 };
 
 /* The subset of the reference's Typesafe-Config keys the path consumes
  * (TestSettings.scala:8-45; read at LSH:19-33, Dense:39-58). */

@@ -144,12 +144,14 @@ struct dpf_index {
     DevBuf d_base16e, ws_q16e;               // distances between the rows and their fp16 copies
     DevBuf d_base16n, ws_q16n;               // their squared norms
     DevBuf d_slot_norm;                      // the rows' squared norms once more, in bucket order beside d_ids
+    DevBuf d_base16t, d_slot_tail, ws_q16t;  // tails: by row, in bucket order beside d_ids, of the query batch
     DevBuf ws_qc;                            // per-query record of the scan
     DevBuf ws_ovf;                           // queries whose forward list overflowed
     int32_t emit_cap = 8192;                 // entries per forward list
     DevBuf sub_q, sub_qids, sub_ids, sub_scores, sub_ws[6];   // their batch on the gather path
     DevBuf d_base16, ws_q16;                 // fp16 copies of the resident rows / of the query batch
     int ks16 = -1;                           // 32-dimension fp16 steps per padded row (-1: no fp16 scan)
+    int filter_dim = 0;                      // dimensions the fp16 rows keep; the rest (at most 8) travels as 16-byte tails
     int64_t ntiles = 0, nutiles = 0, num_leaves = 0;
     std::vector<uint32_t> h_leaf_len;        // rows per bucket of the uploaded snapshot
     bool bucket_major = false;               // the bucket-major rerank applies to this handle
@@ -249,7 +251,8 @@ extern "C" int dpf_create(const dpf_config *cfg, dpf_index **out)
     ix->dpad = (cfg->dim + per16 - 1) / per16 * per16;
     if (cfg->dtype == DPF_F32 && !(cfg->flags & DPF_FLAG_GATHER_ONLY)) {
         // the bucket-major scan works on fp16 copies of up to 1024 dimensions
-        ix->ks16 = leafscan_f16_steps(cfg->dim);
+        ix->filter_dim = (cfg->flags & DPF_FLAG_FULL_FILTER) ? cfg->dim : leafscan_f16_filter_dim(cfg->dim, cfg->metric);
+        ix->ks16 = leafscan_f16_steps(ix->filter_dim);
         ix->bucket_major = ix->ks16 > 0;
     }
     if (ix->dpad * (int64_t)ix->elem / 16 > rerank_max_chunks16()) { delete ix; return fail(nullptr, DPF_EINVAL, "dpf_create: dim too large for the rerank kernel"); }
@@ -312,7 +315,7 @@ extern "C" void dpf_destroy(dpf_index *ix)
     for (int i = 0; i < 4; i++) if (ix->ev_scan[i]) (void)hipEventDestroy(ix->ev_scan[i]);
     DevBuf *more[] = {&ix->ws_emit_ucnt, &ix->ws_emit_v, &ix->ws_leaf_units, &ix->ws_unit_off, &ix->ws_q_leaves, &ix->ws_q_leaf_cnt, &ix->d_leaf_tile0, &ix->ws_units, &ix->d_tiles, &ix->ws_lq_off, &ix->ws_lq_cursor, &ix->ws_leaf_queries,
                       &ix->ws_seed_cand, &ix->ws_seed_cnt, &ix->ws_seed_ids, &ix->ws_seed_scores, &ix->ws_emit, &ix->ws_emit_cnt,
-                      &ix->d_base16, &ix->ws_q16, &ix->d_base16n, &ix->ws_q16n, &ix->d_base16e, &ix->ws_q16e, &ix->ws_flag, &ix->ws_tau, &ix->ws_qc, &ix->d_slot_norm, &ix->ws_ovf, &ix->sub_q, &ix->sub_qids, &ix->sub_ids,
+                      &ix->d_base16, &ix->ws_q16, &ix->d_base16n, &ix->ws_q16n, &ix->d_base16e, &ix->ws_q16e, &ix->ws_flag, &ix->ws_tau, &ix->ws_qc, &ix->d_slot_norm, &ix->d_base16t, &ix->d_slot_tail, &ix->ws_q16t, &ix->ws_ovf, &ix->sub_q, &ix->sub_qids, &ix->sub_ids,
                       &ix->sub_scores, &ix->sub_ws[0], &ix->sub_ws[1], &ix->sub_ws[2], &ix->sub_ws[3], &ix->sub_ws[4], &ix->sub_ws[5]};
     for (DevBuf *b : more) b->release();
     delete ix;
@@ -501,8 +504,11 @@ static int upload_snapshot(dpf_index *ix, ForestSnapshot &s)
     ix->part_counts = s.part_counts;
     if (ix->bucket_major && ix->ks16 > 0 && ix->ntiles > 0 && ix->base_rows > 0) {
         HIPCHECK(ix, ix->d_slot_norm.ensure(std::max<size_t>(ix->d_ids.cap, 16)));
+        const bool tails = ix->filter_dim < ix->cfg.dim;
+        if (tails) HIPCHECK(ix, ix->d_slot_tail.ensure(std::max<size_t>(ix->d_ids.cap, 16) * 4));
         launch_tile_maxnorm((uint4 *)ix->d_tiles.p, ix->nutiles, ix->d_ids.as<int32_t>(), ix->d_base16n.as<float>(), ix->d_base16e.as<float>(),
-                            ix->row_begin, ix->row_begin + ix->base_rows, ix->d_slot_norm.as<float>(), nullptr);
+                            ix->row_begin, ix->row_begin + ix->base_rows, ix->d_slot_norm.as<float>(), nullptr,
+                            tails ? (const uint4 *)ix->d_base16t.p : nullptr, tails ? (uint4 *)ix->d_slot_tail.p : nullptr);
         HIPCHECK(ix, hipDeviceSynchronize());
     }
     return DPF_OK;
@@ -566,8 +572,11 @@ static int device_snapshot(dpf_index *ix, int64_t total)
     ix->part_counts = f.part_counts;
     if (ix->bucket_major && ix->ks16 > 0 && ix->ntiles > 0 && ix->base_rows > 0) {
         HIPCHECK(ix, ix->d_slot_norm.ensure(std::max<size_t>(ix->d_ids.cap, 16)));
+        const bool tails = ix->filter_dim < ix->cfg.dim;
+        if (tails) HIPCHECK(ix, ix->d_slot_tail.ensure(std::max<size_t>(ix->d_ids.cap, 16) * 4));
         launch_tile_maxnorm((uint4 *)ix->d_tiles.p, ix->nutiles, ix->d_ids.as<int32_t>(), ix->d_base16n.as<float>(), ix->d_base16e.as<float>(),
-                            ix->row_begin, ix->row_begin + ix->base_rows, ix->d_slot_norm.as<float>(), nullptr);
+                            ix->row_begin, ix->row_begin + ix->base_rows, ix->d_slot_norm.as<float>(), nullptr,
+                            tails ? (const uint4 *)ix->d_base16t.p : nullptr, tails ? (uint4 *)ix->d_slot_tail.p : nullptr);
         HIPCHECK(ix, hipDeviceSynchronize());
     }
     return DPF_OK;
@@ -584,8 +593,10 @@ static int finish_fit(dpf_index *ix, int64_t total, int64_t new_rows)
         HIPCHECK(ix, ix->d_base16.ensure((size_t)new_rows * ix->ks16 * 32 * 2));
         HIPCHECK(ix, ix->d_base16n.ensure((size_t)new_rows * 4));
         HIPCHECK(ix, ix->d_base16e.ensure((size_t)new_rows * 4));
-        launch_rows_to_f16(ix->d_base.as<float>(), ix->dpad, d, new_rows, ix->d_base16.as<uint16_t>(), ix->ks16 * 32,
-                            ix->d_base16n.as<float>(), ix->d_base16e.as<float>(), nullptr);
+        const bool tails = ix->filter_dim < d;
+        if (tails) HIPCHECK(ix, ix->d_base16t.ensure((size_t)new_rows * 16));
+        launch_rows_to_f16(ix->d_base.as<float>(), ix->dpad, std::min(d, ix->filter_dim), new_rows, ix->d_base16.as<uint16_t>(), ix->ks16 * 32,
+                            ix->d_base16n.as<float>(), ix->d_base16e.as<float>(), nullptr, nullptr, d, tails ? (uint4 *)ix->d_base16t.p : nullptr);
     }
     HIPCHECK(ix, hipDeviceSynchronize());
     ix->base_rows = new_rows;
@@ -1164,8 +1175,10 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
         TauParams tp;
         tp.metric = ix->cfg.metric; tp.seed_scores = ix->ws_seed_scores.as<double>(); tp.seed_ids = ix->ws_seed_ids.as<int32_t>();
         tp.k = k; tp.qids = d_qids; tp.tau = ix->ws_tau.as<int32_t>(); tp.qc = (float4 *)ix->ws_qc.p;
-        launch_rows_to_f16((const float *)qpad, ix->dpad, ix->cfg.dim, nq, ix->ws_q16.as<uint16_t>(), ix->ks16 * 32,
-                           ix->ws_q16n.as<float>(), ix->ws_q16e.as<float>(), stream, &tp);
+        const bool tails = ix->filter_dim < ix->cfg.dim;
+        if (tails) HIPCHECK(ix, ix->ws_q16t.ensure((size_t)nq * 16));
+        launch_rows_to_f16((const float *)qpad, ix->dpad, std::min(ix->cfg.dim, ix->filter_dim), nq, ix->ws_q16.as<uint16_t>(), ix->ks16 * 32,
+                           ix->ws_q16n.as<float>(), ix->ws_q16e.as<float>(), stream, &tp, ix->cfg.dim, tails ? (uint4 *)ix->ws_q16t.p : nullptr);
     }
     if (!carried) HIPCHECK(ix, ix->ws_units.ensure((size_t)std::max<int64_t>(nunits + nunits / 2, 1024) * 16));
     launch_units(lq_cnt_of(ix), ix->ws_lq_off.as<int64_t>(), ix->d_leaf_tile0.as<uint32_t>(),
@@ -1186,6 +1199,7 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     lp.slot_norm = ix->d_slot_norm.as<float>(); lp.qc = (const float4 *)ix->ws_qc.p;
     lp.units = (const uint4 *)ix->ws_units.p;
     lp.num_cus = ix->num_cus; lp.ks = ix->ks16;
+    if (ix->filter_dim < ix->cfg.dim) { lp.slot_tail = (const uint4 *)ix->d_slot_tail.p; lp.q_tail = (const uint4 *)ix->ws_q16t.p; }
     lp.num_counters = TICKET_COUNTERS;
     lp.tickets = (unsigned int *)(flag_block_of(ix) + 128);
     // a first slice of the units, then thresholds refined from what it forwarded, then the rest
@@ -1662,7 +1676,8 @@ extern "C" int dpf_last_rerank_profile(dpf_index *ix, double *ms, int64_t *algor
         for (size_t l = 0; l < c.size(); l++)
             if (c[l]) touched_rows += ix->h_leaf_len[l];
         const int64_t srow = (int64_t)ix->ks16 * 64;
-        if (algorithmic_bytes) *algorithmic_bytes = touched_rows * (srow + 8) + ix->st.last_pairs * (srow + 24) + uniq * 8;
+        const int64_t tail = ix->filter_dim < ix->cfg.dim ? 16 : 0;        // the 16-byte tails of cut rows and query rows
+        if (algorithmic_bytes) *algorithmic_bytes = touched_rows * (srow + 8 + tail) + ix->st.last_pairs * (srow + 24 + tail) + uniq * 8;
         return DPF_OK;
     }
     // gather rerank: candidate rows + candidate ids + query rows + (score, id) results

@@ -99,6 +99,10 @@ struct LeafScanParams {
     unsigned int *tickets;       // num_counters ticket counters of this launch, 32 words apart, zeroed
     int32_t num_counters;
     int32_t ks;
+    // l2, rows cut at a row length the scan has a kernel for (leafscan_f16_filter_dim): the up to 8 dimensions behind the
+    // cut, fp16, zero padded - the tile's in bucket order beside ids[], the queries' by query; nullptr: whole rows
+    const uint4 *slot_tail = nullptr;
+    const uint4 *q_tail = nullptr;
 };
 
 struct RerankParams {
@@ -146,8 +150,9 @@ void launch_bucket_scans(const uint32_t *lq_cnt, const uint32_t *leaf_tile0, int
 void launch_units(const uint32_t *lq_cnt, const int64_t *lq_off, const uint32_t *leaf_tile0, const uint4 *tiles, int64_t ntiles,
                   const int64_t *unit_off, uint4 *units, const int32_t *abort, hipStream_t stream);
 void launch_tile_maxnorm(uint4 *tiles, int64_t ntiles, const int32_t *ids, const float *norms, const float *errs, int64_t row_begin,
-                         int64_t row_end, float *slot_norms, hipStream_t stream);
+                         int64_t row_end, float *slot_norms, hipStream_t stream, const uint4 *tails = nullptr, uint4 *slot_tails = nullptr);
 int leafscan_f16_steps(int dim);
+int leafscan_f16_filter_dim(int dim, int metric);
 int leafscan_tile_rows(int ks);
 void launch_refine(int metric, const int32_t *emit, const float *emit_v, const int32_t *emit_cnt, int32_t cap, int k, int64_t nq,
                    const float *q16_err, int32_t *tau, hipStream_t stream);
@@ -162,8 +167,11 @@ struct TauParams {
     int32_t *tau = nullptr;                // [nq]
     float4 *qc = nullptr;                  // [nq]
 };
+// dim_all > dim: the dimensions [dim, dim_all) (at most 8) go to tails[r] instead of the row; norms cover the row,
+// errs all dim_all dimensions
 void launch_rows_to_f16(const float *src, int64_t src_stride, int dim, int64_t n, uint16_t *dst, int dst_stride,
-                         float *norms, float *errs, hipStream_t stream, const TauParams *tau = nullptr);
+                         float *norms, float *errs, hipStream_t stream, const TauParams *tau = nullptr, int dim_all = 0,
+                         uint4 *tails = nullptr);
 size_t unique_lists_lds(int32_t longest);
 void launch_unique_lists(int32_t *emit, const int32_t *emit_cnt, int32_t cap, int32_t longest, int32_t *unique_cnt, int64_t nq,
                          hipStream_t stream);

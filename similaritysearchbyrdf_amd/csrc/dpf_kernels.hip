@@ -1140,7 +1140,8 @@ __device__ inline uint32_t ceil16_bits(float f)
 // norms as one 256-byte run instead of 64 scattered 4-byte reads that each pull a whole line.
 __global__ __launch_bounds__(256) void k_tile_maxnorm(uint4 *__restrict__ tiles, int64_t ntiles, const int32_t *__restrict__ ids,
                                                       const float *__restrict__ norms, const float *__restrict__ errs,
-                                                      int64_t row_begin, int64_t row_end, float *__restrict__ slot_norms)
+                                                      int64_t row_begin, int64_t row_end, float *__restrict__ slot_norms,
+                                                      const uint4 *__restrict__ tails, uint4 *__restrict__ slot_tails)
 {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= ntiles) return;
@@ -1149,8 +1150,13 @@ __global__ __launch_bounds__(256) void k_tile_maxnorm(uint4 *__restrict__ tiles,
     for (uint32_t i = 0; i < td.z; i++) {
         const int64_t id = ids[td.y + i];
         float nn = 0.f;
-        if (id >= row_begin && id < row_end) { nn = norms[id - row_begin]; m = fmaxf(m, nn); e = fmaxf(e, errs[id - row_begin]); }
+        uint4 tl = make_uint4(0u, 0u, 0u, 0u);
+        if (id >= row_begin && id < row_end) {
+            nn = norms[id - row_begin]; m = fmaxf(m, nn); e = fmaxf(e, errs[id - row_begin]);
+            if (tails) tl = tails[id - row_begin];
+        }
         slot_norms[td.y + i] = nn;
+        if (slot_tails) slot_tails[td.y + i] = tl;
     }
     td.w = ceil16_bits(sqrtf(m) * 1.00001f) | (ceil16_bits(e) >> 16);
     tiles[t] = td;
@@ -1162,9 +1168,9 @@ void launch_units(const uint32_t *lq_cnt, const int64_t *lq_off, const uint32_t 
     if (ntiles > 0) hipLaunchKernelGGL(k_units, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, stream, lq_cnt, lq_off, leaf_tile0, tiles, ntiles, unit_off, units, abort);
 }
 void launch_tile_maxnorm(uint4 *tiles, int64_t ntiles, const int32_t *ids, const float *norms, const float *errs, int64_t row_begin,
-                         int64_t row_end, float *slot_norms, hipStream_t stream)
+                         int64_t row_end, float *slot_norms, hipStream_t stream, const uint4 *tails, uint4 *slot_tails)
 {
-    if (ntiles > 0) hipLaunchKernelGGL(k_tile_maxnorm, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, stream, tiles, ntiles, ids, norms, errs, row_begin, row_end, slot_norms);
+    if (ntiles > 0) hipLaunchKernelGGL(k_tile_maxnorm, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, stream, tiles, ntiles, ids, norms, errs, row_begin, row_end, slot_norms, tails, slot_tails);
 }
 
 // Ablation switches of the scan (timing experiments that give wrong answers on purpose) exist only in
@@ -1192,6 +1198,16 @@ __device__ __forceinline__ float best_of(const f32x4 (&acc)[RB], int r)
     return m;
 }
 
+// 16-byte tails (8 fp16 values, see leafscan_f16_filter_dim): inner product in fp32 (exact products)
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float tail_dot(const uint4 &a, const uint4 &b)
+{
+    float c = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, a.x), __builtin_bit_cast(f16x2, b.x), 0.f, false);
+    c = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, a.y), __builtin_bit_cast(f16x2, b.y), c, false);
+    c = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, a.z), __builtin_bit_cast(f16x2, b.z), c, false);
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, a.w), __builtin_bit_cast(f16x2, b.w), c, false);
+}
+
 // The queries of one unit against the tile a wave holds in registers, 16 at a time: thresholds,
 // products on the matrix cores, tests, forwarding.  s_* are this wave's LDS areas: forwarded (query,
 // id, bound) triples parked until 64 are there; per query slot the threshold G, and for the rare
@@ -1208,12 +1224,22 @@ __device__ __forceinline__ float best_of(const f32x4 (&acc)[RB], int r)
 //        q~.x~ + that slack >= tau.
 // G2 is the level at which a row is roughly inside 0.985 of the k-th best distance; it only
 // triggers the exact selection below, so it needs no rigour.
-template <int KS, int METRIC, int RB>
+//
+// TAIL (l2 only): the rows and query rows are cut at KS * 32 dimensions and xt[rb] / q_tail hold the up to 8
+// dimensions behind the cut.  The matrix cores' d then belongs to the cut vectors, whose distance bounds the whole
+// one from below: the test d >= G lets through every row the whole-row test would.  For the scores that pass it the
+// tail's share t2 = |q_t - x_t|^2 = |q_t|^2 + |x_t|^2 - 2 q_t.x_t (fp32 from exact fp16 products; its rounding,
+// at most a few fp32 ulps of |q_t|^2 + |x_t|^2, is covered by the slack 2e-6 (|q_t|^2 + |x_t|^2)) is put back:
+// d - t2_lo / 2 is the d of the whole fp16 rows (rounded towards keeping the row), s_hi + t2_hi their squared
+// distance from above.  Norms in the thresholds are the cut vectors', rounding distances the whole rows'.
+template <int KS, int METRIC, int RB, bool TAIL>
 __device__ __forceinline__ void leafscan_chunks(const LeafScanParams &p, const uint16_t *__restrict__ Q16, const f16x8 (&xb)[RB][KS],
                                                 const float (&nJ)[RB], const int32_t (&idj)[RB], uint32_t rows, uint32_t nq,
                                                 uint32_t lq0, float xrm, float cxm, int32_t qsc, int32_t qsn, int32_t *s_fq,
-                                                int32_t *s_fid, float *s_fv, float4 *s_slot, float *s_G, int32_t *s_qid, int &nbuf)
+                                                int32_t *s_fid, float *s_fv, float4 *s_slot, float *s_G, int32_t *s_qid, int &nbuf,
+                                                const uint4 *s_xt, uint4 *s_qt, float *s_qt2)
 {
+    static_assert(!TAIL || METRIC == 1, "tails belong to the l2 filter");
     static_assert(RB == 4 || RB == 1, "64-row tiles, or 16-row tiles for rows of more than 768 dimensions");
     // Rows of more than 8 steps: a 64-row tile still pays (one wave per SIMD holds it in the 512 registers
     // of its lanes; sharing a tile's rows among 4x the queries outweighs the lost occupancy: 1.4-1.5x
@@ -1245,6 +1271,8 @@ __device__ __forceinline__ void leafscan_chunks(const LeafScanParams &p, const u
         for (int t = 0; t < QS; t++) qa[t] = *(const f16x8 *)(qrow + 32 * t);
         const float m_tau = dec_f32(__hip_atomic_load(&p.tau[qat], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         const float4 qc = p.qc[qat];
+        uint4 qtv = make_uint4(0u, 0u, 0u, 0u);
+        if (TAIL && g == 0) qtv = p.q_tail[qat];
         const int32_t qcur = qsc;
         // query indices two chunks ahead
         qsc = qsn;
@@ -1268,6 +1296,7 @@ __device__ __forceinline__ void leafscan_chunks(const LeafScanParams &p, const u
                 s_G[i16] = G;
                 s_slot[i16] = make_float4(G2, __int_as_float(qcur), aux, qc.z);
                 s_qid[i16] = __float_as_int(qc.w);
+                if (TAIL) { s_qt[i16] = qtv; s_qt2[i16] = tail_dot(qtv, qtv); }
             }
         }
         f32x4 acc[RB];
@@ -1320,19 +1349,31 @@ __device__ __forceinline__ void leafscan_chunks(const LeafScanParams &p, const u
             if (__ballot(best_of<RB>(acc, r) >= Gr) == 0) continue;
             const float4 sc = s_slot[slot];           // {G2, query index, |q - q~| or slack, |q~|^2}
             const int32_t qq = __float_as_int(sc.y), qidq = s_qid[slot];
+            // the tail's share of the squared distance of row block rb to this slot's query, from below and from above
+            uint4 qt = make_uint4(0u, 0u, 0u, 0u);
+            float qt2 = 0.f;
+            if (TAIL) { qt = s_qt[slot]; qt2 = s_qt2[slot]; }
+            auto tail2 = [&](int rb, float &lo, float &hi) {
+                lo = 0.f; hi = 0.f;
+                if (TAIL) {
+                    const uint4 x = s_xt[rb * 16 + i16];
+                    const float ab = qt2 + tail_dot(x, x);
+                    const float t2 = fmaxf(fmaf(-2.0f, tail_dot(qt, x), ab), 0.f), slack = 2e-6f * ab;
+                    lo = fmaxf(t2 - slack, 0.f);
+                    hi = t2 + slack;
+                }
+            };
             int tight = 0;                            // this lane's rows inside the trigger level
-            if (METRIC == 1) {
-#pragma unroll
-                for (int rb = 0; rb < RB; rb++) tight += acc[rb][r] >= sc.x ? 1 : 0;
-            }
-            if (METRIC == 1 && __ballot(tight != 0)) {
-                // rows of the 16-lane group (one query) inside the trigger level
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) tight += __shfl_xor(tight, o);
-            }
 #pragma unroll
             for (int rb = 0; rb < RB; rb++) {
-                const bool fwd = acc[rb][r] >= Gr && !self_excluded(idj[rb], qidq, p.exclude_self);
+                // first stage: the matrix cores' score of the (cut) rows; second stage, for those that pass: the tail put back
+                const bool first = acc[rb][r] >= Gr;
+                if (__ballot(first) == 0) continue;
+                float t2lo, t2hi;
+                tail2(rb, t2lo, t2hi);
+                const float d2 = fmaf(-0.5f, t2lo, acc[rb][r]);
+                if (METRIC == 1) tight += first && d2 >= sc.x ? 1 : 0;
+                const bool fwd = first && d2 >= Gr && !self_excluded(idj[rb], qidq, p.exclude_self);
                 const unsigned long long m = __ballot(fwd);
                 if (m) {
                     if (fwd) {
@@ -1344,7 +1385,7 @@ __device__ __forceinline__ void leafscan_chunks(const LeafScanParams &p, const u
                         // sqrt(exact distance) <= sqrt(s_hi) + |x - x~|max + |q - q~|, the query's share is added by
                         // the reader; dot: exact product >= q~.x~ - slack
                         if (METRIC == 1) {
-                            const float s_hi = fmaf(-2.0f, acc[rb][r], sc.w * (1.0f + c32) - 4.001f * c32 * nJ[rb]);
+                            const float s_hi = fmaf(-2.0f, acc[rb][r], sc.w * (1.0f + c32) - 4.001f * c32 * nJ[rb]) + t2hi;
                             s_fv[at] = sqrtf(fmaxf(s_hi, 0.f) * 1.000001f) * 1.000001f + cxm;
                         } else {
                             s_fv[at] = acc[rb][r] - sc.z * 1.000001f;
@@ -1362,6 +1403,11 @@ __device__ __forceinline__ void leafscan_chunks(const LeafScanParams &p, const u
                     }
                 }
             }
+            if (METRIC == 1 && __ballot(tight != 0)) {
+                // rows of the 16-lane group (one query) inside the trigger level
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) tight += __shfl_xor(tight, o);
+            }
             if (METRIC == 1 && tight >= p.k && !DPF_ABLATION(p, 4)) {
                 // Roughly k or more rows of this tile sit inside 0.985 of the k-th best distance.  With
                 //   v = sqrt(s_hi) + |x - x~|max >= sqrt(exact distance) - |q - q~|
@@ -1371,7 +1417,9 @@ __device__ __forceinline__ void leafscan_chunks(const LeafScanParams &p, const u
 #pragma unroll
                 for (int rb = 0; rb < RB; rb++) {
                     const bool ok = idj[rb] >= 0 && !self_excluded(idj[rb], qidq, p.exclude_self);
-                    const float s_hi = fmaf(-2.0f, acc[rb][r], sc.w * (1.0f + c32) - 4.001f * c32 * nJ[rb]);
+                    float t2lo, t2hi;
+                    tail2(rb, t2lo, t2hi);
+                    const float s_hi = fmaf(-2.0f, acc[rb][r], sc.w * (1.0f + c32) - 4.001f * c32 * nJ[rb]) + t2hi;
                     v[rb] = ok ? sqrtf(fmaxf(s_hi, 0.f) * 1.000001f) * 1.000001f + cxm : HUGE_VALF;
                 }
                 // rank of each of this lane's RB values among the group's 16*RB, one value at a time: the path
@@ -1420,10 +1468,13 @@ __device__ __forceinline__ void leafscan_flush_rest(const LeafScanParams &p, con
 // were 1.9x slower in spite of the higher occupancy).
 constexpr int ls16_waves(int ks, int rb) { return ks > 8 && rb == 4 ? 1 : ks >= 8 ? 2 : LS16_WAVES4; }
 
-template <int KS, int METRIC, int RB>
+template <int KS, int METRIC, int RB, bool TAIL>
 __global__ __launch_bounds__(256, ls16_waves(KS, RB)) void k_leafscan_f16(LeafScanParams p, const uint16_t *__restrict__ Q16,
                                                                           const uint16_t *__restrict__ B16)
 {
+    __shared__ uint4 s_qt[4][TAIL ? 16 : 1];              // the chunk's query tails and their squared norms
+    __shared__ float s_qt2[4][TAIL ? 16 : 1];
+    __shared__ uint4 s_xt[4][TAIL ? 64 : 1];              // the tile's row tails
     __shared__ int32_t s_fq[4][128], s_fid[4][128];
     __shared__ float s_fv[4][128];
     __shared__ float4 s_slot[4][16];
@@ -1488,6 +1539,17 @@ __global__ __launch_bounds__(256, ls16_waves(KS, RB)) void k_leafscan_f16(LeafSc
                                                           // -inf for an absent row, which then never reaches any threshold
         const uint32_t rows = U0.y & 0xffu;               // 16-row blocks past the tile's end are skipped throughout
         const uint32_t tile_slot0 = U0.x;
+        if (TAIL) {
+            // the tile's tails go straight to LDS (no registers): 16 lanes x 16 bytes per 16-row block, requested before
+            // the rows, so that the wait for the rows (loads complete in order) covers them
+#pragma unroll
+            for (int rb = 0; rb < RB; rb++) {
+                if (rb * 16u >= rows && rb > 0) continue;
+                if (g == 0 && rb * 16u + (uint32_t)i16 < rows)
+                    __builtin_amdgcn_global_load_lds(p.slot_tail + tile_slot0 + rb * 16u + (uint32_t)i16,
+                                                     (__attribute__((address_space(3))) void *)(s_xt[wave] + rb * 16), 16, 0, 0);
+            }
+        }
 #pragma unroll
         for (int rb = 0; rb < RB; rb++) {
             if (rb * 16u >= rows && rb > 0) continue;
@@ -1517,8 +1579,8 @@ __global__ __launch_bounds__(256, ls16_waves(KS, RB)) void k_leafscan_f16(LeafSc
         u_after = unit_of(3u * places + (uint32_t)__builtin_amdgcn_readfirstlane((int)pend));
         if (lane == 0) pend = atomicAdd(ctr, 1u);
         small(U0, id0, qs0);
-        leafscan_chunks<KS, METRIC, RB>(p, Q16, xb, nJ, idj, rows, nq, lq0, xrm, cxm, qsc, qsn, s_fq[wave], s_fid[wave], s_fv[wave],
-                                        s_slot[wave], s_G[wave], s_qid[wave], nbuf);
+        leafscan_chunks<KS, METRIC, RB, TAIL>(p, Q16, xb, nJ, idj, rows, nq, lq0, xrm, cxm, qsc, qsn, s_fq[wave], s_fid[wave], s_fv[wave],
+                                              s_slot[wave], s_G[wave], s_qid[wave], nbuf, s_xt[wave], s_qt[wave], s_qt2[wave]);
     }
     leafscan_flush_rest(p, s_fq[wave], s_fid[wave], s_fv[wave], nbuf);
 }
@@ -1532,11 +1594,18 @@ static void launch_leafscan_f16_m(const LeafScanParams &p, hipStream_t stream)
     dim3 grid((unsigned)std::min<int64_t>((n + 3) / 4, resident)), block(256);
     LeafScanParams q = p;
     q.num_counters = (int32_t)std::min<int64_t>(p.num_counters, grid.x);     // every counter needs a workgroup
-#define DPF_LB(KS) hipLaunchKernelGGL((k_leafscan_f16<KS, METRIC, RB>), grid, block, 0, stream, q, q.Q16, q.base16)
+#define DPF_LB(KS)                                                                                                       \
+    do {                                                                                                                 \
+        if constexpr (METRIC == 1) {                                                                                     \
+            if (q.slot_tail) { hipLaunchKernelGGL((k_leafscan_f16<KS, METRIC, RB, true>), grid, block, 0, stream, q, q.Q16, q.base16); break; } \
+        }                                                                                                                \
+        hipLaunchKernelGGL((k_leafscan_f16<KS, METRIC, RB, false>), grid, block, 0, stream, q, q.Q16, q.base16);         \
+    } while (0)
     if constexpr (RB == 4) {
         switch (p.ks) {
         case 1: DPF_LB(1); break;
         case 2: DPF_LB(2); break;
+        case 3: DPF_LB(3); break;
         case 4: DPF_LB(4); break;
         case 8: DPF_LB(8); break;
         case 16: DPF_LB(16); break;
@@ -1606,18 +1675,36 @@ void launch_refine(int metric, const int32_t *emit, const float *emit_v, const i
     else hipLaunchKernelGGL((k_refine<1>), grid, block, 0, stream, emit, emit_v, emit_cnt, cap, k, nq, q16_err, tau);
 }
 
-// fp16 steps (of 32 dimensions) a padded row takes: 1, 2, 4, 8 (64-row tiles), 16, 24 or 32 (16-row tiles);
+// fp16 steps (of 32 dimensions) a padded row takes: 1, 2, 3, 4, 8 (64-row tiles), 16, 24 or 32 (16-row tiles);
 // -1 when the row is too long
 int leafscan_f16_steps(int dim)
 {
     const int ks = (dim + 31) / 32;
     if (ks <= 1) return 1;
     if (ks <= 2) return 2;
+    if (ks <= 3) return 3;
     if (ks <= 4) return 4;
     if (ks <= 8) return 8;
     if (ks <= 16) return 16;
     if (ks <= 24) return 24;
     return ks <= 32 ? 32 : -1;
+}
+
+// Dimensions the fp16 rows of the scan keep (l2 metric).  The scan's rate is set by the 64-byte requests its rows
+// cost, and a row of 100 dimensions padded to 128 costs four of them for little more than three requests' worth of
+// data.  When at most 8 dimensions (and at most a sixteenth of the row) stick out over a row length the scan has a
+// kernel for, the rows are cut there - 100 -> 96 (192-byte rows), 136 -> 128, 260 -> 256, 770 -> 768 - and the
+// dimensions behind the cut travel as a 16-byte tail per row.  The squared distance over the leading dimensions
+// bounds the whole one from below, so the matrix cores' test on the cut rows lets every row through that the test
+// on whole rows would; for the few scores that pass it the tail's share |q_t - x_t|^2 is added on the vector ALU,
+// which gives the whole-row fp16 distance again: the same filter, in two stages.
+int leafscan_f16_filter_dim(int dim, int metric)
+{
+    if (metric != 1) return dim;
+    const int t = dim / 32, rest = dim - 32 * t;
+    if (t < 1 || rest == 0 || rest > 8 || rest * 16 > dim) return dim;
+    const bool has_kernel = t == 1 || t == 2 || t == 3 || t == 4 || t == 8 || t == 16 || t == 24 || t == 32;
+    return has_kernel ? 32 * t : dim;
 }
 
 // First threshold and the per-query record the scan reads (see leafscan_chunks), written by the lane that finishes a
@@ -1641,10 +1728,32 @@ __device__ __forceinline__ void write_tau(const TauParams &t, int64_t q, float q
 // multiple of 32), round to nearest even, zero padded; norms[r] = sum of the squares of the ROUNDED
 // elements of row r, accumulated in fp32; errs[r] = an upper bound of |row - rounded row| (the
 // element differences are exact in fp32).  One lane converts 8 consecutive elements.
+// nearest fp16 of x, clamped to the finite range, would-be subnormals flushed to zero; err2 gathers (x - fp16)^2
+__device__ __forceinline__ uint16_t to_f16_measured(float x, float &sq, float &err2)
+{
+    _Float16 h = (_Float16)fminf(fmaxf(x, -65504.0f), 65504.0f);
+    if (fabsf((float)h) < 6.103515625e-5f) h = (_Float16)0.0f;
+    const float f = (float)h;
+    sq = fmaf(f, f, sq);
+    const float df = x - f;
+    err2 = fmaf(df, df, err2);
+    return __builtin_bit_cast(uint16_t, h);
+}
+
+// the dimensions [dim, dim_all) of row r (at most 8) as one 16-byte tail, zero padded; their rounding distance joins err2
+__device__ __forceinline__ void tail_to_f16(const float *__restrict__ row, int dim, int dim_all, uint4 *__restrict__ out, float &err2)
+{
+    uint16_t o[8];
+    float unused = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; e++) o[e] = dim + e < dim_all ? to_f16_measured(row[dim + e], unused, err2) : (uint16_t)0;
+    *out = make_uint4(o[0] | ((uint32_t)o[1] << 16), o[2] | ((uint32_t)o[3] << 16), o[4] | ((uint32_t)o[5] << 16), o[6] | ((uint32_t)o[7] << 16));
+}
+
 template <bool TAU>
 __global__ void k_rows_to_f16(const float *__restrict__ src, int64_t src_stride, int dim, int64_t n,
                                uint16_t *__restrict__ dst, int dst_stride, float *__restrict__ norms, float *__restrict__ errs,
-                               TauParams tp)
+                               TauParams tp, int dim_all, uint4 *__restrict__ tails)
 {
     const int per_row = dst_stride >> 3;                  // lanes per row: a power of two up to 64
     const int64_t total = n * per_row;
@@ -1675,6 +1784,7 @@ __global__ void k_rows_to_f16(const float *__restrict__ src, int64_t src_stride,
         w.x = o[0] | ((uint32_t)o[1] << 16); w.y = o[2] | ((uint32_t)o[3] << 16);
         w.z = o[4] | ((uint32_t)o[5] << 16); w.w = o[6] | ((uint32_t)o[7] << 16);
         *(uint4 *)(dst + i * 8) = w;
+        if (tails && c0 == 0) tail_to_f16(src + r * src_stride, dim, dim_all, tails + r, ee);
     }
     for (int m = 1; m < per_row; m <<= 1) { ss += __shfl_xor(ss, m); ee += __shfl_xor(ee, m); }   // rows never straddle a wave
     if (live && c0 == 0) {
@@ -1688,12 +1798,13 @@ __global__ void k_rows_to_f16(const float *__restrict__ src, int64_t src_stride,
 template <bool TAU>
 __global__ __launch_bounds__(256) void k_rows_to_f16_long(const float *__restrict__ src, int64_t src_stride, int dim, int64_t n,
                                                           uint16_t *__restrict__ dst, int dst_stride, float *__restrict__ norms,
-                                                          float *__restrict__ errs, TauParams tp)
+                                                          float *__restrict__ errs, TauParams tp, int dim_all, uint4 *__restrict__ tails)
 {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= n) return;                                   // whole waves leave together
     float ss = 0.f, ee = 0.f;
+    if (tails && lane == 0) tail_to_f16(src + r * src_stride, dim, dim_all, tails + r, ee);
     for (int c0 = lane * 8; c0 < dst_stride; c0 += 512) {
         uint16_t o[8];
 #pragma unroll
@@ -1723,21 +1834,22 @@ __global__ __launch_bounds__(256) void k_rows_to_f16_long(const float *__restric
     }
 }
 void launch_rows_to_f16(const float *src, int64_t src_stride, int dim, int64_t n, uint16_t *dst, int dst_stride,
-                         float *norms, float *errs, hipStream_t stream, const TauParams *tau)
+                         float *norms, float *errs, hipStream_t stream, const TauParams *tau, int dim_all, uint4 *tails)
 {
     if (n <= 0) return;
+    if (!tails || dim_all <= dim) { tails = nullptr; dim_all = dim; }
     const int per_row = dst_stride / 8;
     const TauParams tp = tau ? *tau : TauParams();
     if (per_row > 64 || (per_row & (per_row - 1)) != 0) {
         const dim3 grid((unsigned)((n + 3) / 4)), block(256);
-        if (tau) hipLaunchKernelGGL((k_rows_to_f16_long<true>), grid, block, 0, stream, src, src_stride, dim, n, dst, dst_stride, norms, errs, tp);
-        else hipLaunchKernelGGL((k_rows_to_f16_long<false>), grid, block, 0, stream, src, src_stride, dim, n, dst, dst_stride, norms, errs, tp);
+        if (tau) hipLaunchKernelGGL((k_rows_to_f16_long<true>), grid, block, 0, stream, src, src_stride, dim, n, dst, dst_stride, norms, errs, tp, dim_all, tails);
+        else hipLaunchKernelGGL((k_rows_to_f16_long<false>), grid, block, 0, stream, src, src_stride, dim, n, dst, dst_stride, norms, errs, tp, dim_all, tails);
         return;
     }
     const int64_t total = n * (dst_stride / 8);
     const dim3 grid((unsigned)((total + 255) / 256)), block(256);
-    if (tau) hipLaunchKernelGGL((k_rows_to_f16<true>), grid, block, 0, stream, src, src_stride, dim, n, dst, dst_stride, norms, errs, tp);
-    else hipLaunchKernelGGL((k_rows_to_f16<false>), grid, block, 0, stream, src, src_stride, dim, n, dst, dst_stride, norms, errs, tp);
+    if (tau) hipLaunchKernelGGL((k_rows_to_f16<true>), grid, block, 0, stream, src, src_stride, dim, n, dst, dst_stride, norms, errs, tp, dim_all, tails);
+    else hipLaunchKernelGGL((k_rows_to_f16<false>), grid, block, 0, stream, src, src_stride, dim, n, dst, dst_stride, norms, errs, tp, dim_all, tails);
 }
 
 void launch_leafscan(int metric, const LeafScanParams &p, hipStream_t stream)

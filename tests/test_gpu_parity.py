@@ -944,3 +944,52 @@ def test_load_shards_of_a_saved_index(tmp_path):
     assert again.stats()["base_bytes"] == part.stats()["base_bytes"]
     with pytest.raises(Exception):
         DpfIndex.load(ppath, row_begin=2000, row_end=5000)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["clustered", "tail_heavy", "tail_only", "huge_tail"])
+@pytest.mark.parametrize("dim,row_bytes", [(33, 64), (34, 64), (66, 128), (68, 128), (97, 192), (100, 192), (102, 192),
+                                          (130, 256), (136, 256), (260, 512), (264, 512), (520, 1024), (770, 1536),
+                                          (776, 1536), (104, 256), (40, 128)])
+def test_cut_rows_with_tails_filter_exactly(kind, dim, row_bytes):
+    # l2 handles whose dimension sticks out over a row length of the scan by at most 8 (and a sixteenth) scan rows
+    # cut at that length and add the tail's share for the scores that pass: the same answers as the whole-row filter
+    # (DPF_FLAG_FULL_FILTER) and as the gather path, bit for bit - also when the tail carries most of the distance,
+    # all of it, or values beyond the fp16 range.  (104 and 40 dimensions: too much sticks out, whole rows.)
+    n, nq = (6000, 100) if dim <= 300 else (3000, 60)
+    params, X, Q, pick = make_problem(n=n, nq=nq, dim=dim, bucket_overflow=40, table_num=2, permutation_num=2, n_clusters=6)
+    cut = dim // 32 * 32
+    rng = np.random.default_rng(dim)
+    if kind == "tail_heavy":
+        X[:, cut:] *= 40.0; Q[:, cut:] *= 40.0
+    elif kind == "tail_only":                       # rows agree with one of six prototypes on the leading dimensions: only the tail tells them apart
+        proto = rng.integers(0, 6, size=n)
+        X[:, :cut] = X[:6][proto][:, :cut]
+        Q[:, :cut] = X[pick][:, :cut]
+    elif kind == "huge_tail":
+        X[:, cut:] *= 3.0e4; Q[:, cut:] *= 3.0e4    # beyond 65504: clamped in the fp16 tail, covered by the measured rounding distance
+    X = np.ascontiguousarray(X, dtype=np.float32); Q = np.ascontiguousarray(Q, dtype=np.float32)
+    fast = DpfIndex(params, metric="l2")
+    full = DpfIndex(dict(params, flags=8), metric="l2")            # DPF_FLAG_FULL_FILTER
+    slow = DpfIndex(dict(params, flags=2), metric="l2")            # DPF_FLAG_GATHER_ONLY
+    for ix in (fast, full, slow):
+        ix.fit(X)
+    assert fast.stats()["base16_bytes"] == n * row_bytes
+    whole = next(v for v in (1, 2, 3, 4, 8, 16, 24, 32) if (dim + 31) // 32 <= v)      # steps of 32 dimensions a whole row takes
+    assert full.stats()["base16_bytes"] == n * whole * 64
+    qids = pick.astype(np.int32)
+    for steps, k in ((1, 10), (3, 1), (0, 64)):
+        fi, fs = fast.query_topk(qids, Q, steps=steps, k=k)
+        # (clamped values make the measured rounding distances huge: the filter forwards everything and the batch may
+        # end on the gather path - still the same answer)
+        assert fast.stats()["last_path"] == 1 or kind == "huge_tail"
+        ui, us = full.query_topk(qids, Q, steps=steps, k=k)
+        si, ss = slow.query_topk(qids, Q, steps=steps, k=k)
+        assert np.array_equal(fi, si) and np.array_equal(fs, ss, equal_nan=True)
+        assert np.array_equal(ui, si) and np.array_equal(us, ss, equal_nan=True)
+    # the two filters use the same fp16 information (their rounding allowances differ a little): about the same number
+    # of rows is forwarded - not the many more a filter blind to the tail would let through
+    f_cut, f_whole = fast.stats()["last_forwarded"], full.stats()["last_forwarded"]
+    assert f_cut <= 1.3 * f_whole + 2 * nq, (f_cut, f_whole)
+    for ix in (fast, full, slow):
+        ix.close()

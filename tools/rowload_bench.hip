@@ -3,6 +3,7 @@
 //   shape 0: the MFMA operand shape: one instruction = 16 rows x 64 bytes (lane -> row l%16, piece l/16)
 //   shape 1: whole rows: one instruction = 4 rows x 256 bytes (lane -> row l/16, piece l%16)
 //   shape 2: shape 1 + transpose through LDS into the MFMA operand shape (swizzled, conflict-free)
+//   shape 3: shape 0 on rows of 192 bytes (three 64-byte requests per row instead of four)
 // Build: hipcc --offload-arch=gfx950 -O3 -o rowload_bench tools/rowload_bench.hip
 #include <hip/hip_runtime.h>
 
@@ -25,7 +26,17 @@ __global__ __launch_bounds__(256, 3) void k_pull(const uint8_t *__restrict__ tab
     u32x4 acc = {0u, 0u, 0u, 0u};
     for (uint32_t t = blockIdx.x * 4u + wave; t < ntiles; t += W) {
         u32x4 x[16];
-        if (SHAPE == 0) {
+        if (SHAPE == 3) {
+            const int i16 = lane & 15, g = lane >> 4;
+#pragma unroll
+            for (int rb = 0; rb < 4; rb++) {
+                const size_t row = (size_t)ids[(size_t)t * 64 + rb * 16 + i16];
+                const uint8_t *p = table + row * 192 + 16 * g;
+#pragma unroll
+                for (int k = 0; k < 3; k++) x[rb * 4 + k] = *(const u32x4 *)(p + 64 * k);
+                x[rb * 4 + 3] = x[rb * 4];
+            }
+        } else if (SHAPE == 0) {
             const int i16 = lane & 15, g = lane >> 4;
 #pragma unroll
             for (int rb = 0; rb < 4; rb++) {
@@ -98,7 +109,7 @@ int main(int argc, char **argv)
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
     const dim3 grid(cus * 3), block(256);
-    for (int shape = 0; shape < 3; shape++) {
+    for (int shape = 0; shape < 4; shape++) {
         if (only >= 0 && shape != only) continue;
         float best = 1e30f;
         for (int rep = 0; rep < 4; rep++) {
@@ -106,14 +117,15 @@ int main(int argc, char **argv)
             if (shape == 0) hipLaunchKernelGGL(k_pull<0>, grid, block, 0, 0, d_table, d_ids, ntiles, d_sink);
             if (shape == 1) hipLaunchKernelGGL(k_pull<1>, grid, block, 0, 0, d_table, d_ids, ntiles, d_sink);
             if (shape == 2) hipLaunchKernelGGL(k_pull<2>, grid, block, 0, 0, d_table, d_ids, ntiles, d_sink);
+            if (shape == 3) hipLaunchKernelGGL(k_pull<3>, grid, block, 0, 0, d_table, d_ids, ntiles, d_sink);
             CK(hipEventRecord(e1));
             CK(hipEventSynchronize(e1));
             float ms;
             CK(hipEventElapsedTime(&ms, e0, e1));
             if (rep > 0 && ms < best) best = ms;
         }
-        printf("shape %d: %u rows x 256 B, %d passes: %.3f ms, %.2f TB/s of row bytes\n", shape, nrows, passes, best,
-               (double)total * 256 / best / 1e9);
+        printf("shape %d: %u rows x %d B, %d passes: %.3f ms, %.2f TB/s of row bytes, %.1f G rows/s\n", shape, nrows, shape == 3 ? 192 : 256,
+               passes, best, (double)total * (shape == 3 ? 192 : 256) / best / 1e9, (double)total / best / 1e6);
     }
     return 0;
 }
