@@ -196,6 +196,8 @@ def main():
     ap.add_argument("--no-host-to-host", action="store_true")
     ap.add_argument("--in-flight", type=int, default=1, choices=[1, 2],
                     help="2: also measure the throughput with two batches in flight on one GPU (reported as value_two_in_flight)")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="dpf_set_option on the handle before the batches, e.g. --option scan_passes=3 (repeatable)")
     ap.add_argument("--full-filter", action="store_true",
                     help="fp16 copies of every dimension (DPF_FLAG_FULL_FILTER) instead of the leading ones: A/B of the truncated filter")
     ap.add_argument("--large-table-rows", type=int, default=4_000_000,
@@ -249,6 +251,9 @@ def main():
     sharded = ShardedDpf(params, n, metric=args.metric, top_k=k, dtype=np.float32, device=local, rank=rank, world=world,
                          mode=None if args.mode == "auto" else args.mode, grid=grid)
     ix = sharded.index
+    for ov in args.option:
+        name, _, value = ov.partition("=")
+        ix.set_option(name, int(value))
     t0 = time.time()
     sharded.fit(X)
     fit_s = time.time() - t0

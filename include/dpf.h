@@ -288,10 +288,13 @@ enum {
     DPF_OPT_FIRST_PASS_PERMILLE = 4, /* share of the scan's work units run before the thresholds are refined (100) */
     DPF_OPT_SEED_SAMPLE = 5,         /* candidates per query scored exactly for the first thresholds (256; 16..4096) */
     DPF_OPT_SHORT_RERANK = 6,        /* 0: short candidate lists use the general rerank kernel too (default 1) */
-    DPF_OPT_PROJECTION_MIN_ROWS = 7  /* batches of at least this many vectors, with dim x num_functions >= 40000, are hashed
+    DPF_OPT_PROJECTION_MIN_ROWS = 7, /* batches of at least this many vectors, with dim x num_functions >= 40000, are hashed
                                         through the matrix-core projection (fp64 MFMA contraction + exact re-evaluation of
                                         undecided rows; same hashes bit for bit); others by the exact vector-ALU kernel alone.
                                         Default 4096; 0 = never; 1 = always, whatever the shape */
+    DPF_OPT_SCAN_PASSES = 8,         /* slices the scan's work units are run in, thresholds refined in between: 2, 3, or
+                                        0 = 3 for rows of 16 steps of 32 dimensions and more, 2 otherwise */
+    DPF_OPT_EARLY_PASS_PERMILLE = 9  /* with 3 passes: share of the units in the first of them (40) */
 };
 int dpf_set_option(dpf_index *ix, int32_t option, int64_t value);
 

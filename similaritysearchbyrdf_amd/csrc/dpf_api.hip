@@ -164,8 +164,9 @@ struct dpf_index {
     DevBuf ws_stage;                                  // fit staging
     DevBuf ws_lq_off, ws_lq_cursor, ws_leaf_queries, ws_seed_cand, ws_seed_cnt, ws_seed_ids,
         ws_seed_scores, ws_emit, ws_emit_cnt, ws_flag, ws_tau;
-    hipEvent_t ev_scan[4]{};                          // first and second pass of the scan
+    hipEvent_t ev_scan[6]{};                          // begin and end of up to three passes of the scan
     int scan_launches = 0;
+    bool ev_scan_used[3] = {false, false, false};
     unsigned long long *d_short_hash = nullptr;
     int64_t *pinned = nullptr;                        // host-pinned scratch (8 x int64)
     bool sizes_carried = false;                       // a bucket-major batch has sized leaf_queries[] / units[] already
@@ -180,6 +181,7 @@ struct dpf_index {
     unsigned char *scratch_ptr = nullptr;             // this device's copy of the static scratch array
     // dpf_set_option values (0 / default = the library's own choice)
     int32_t opt_emit_cap = 0, opt_bucket_list_cap = 0, opt_first_permille = 100, opt_seed_cap = 256;
+    int32_t opt_scan_passes = 0, opt_early_permille = 40;   // passes: 0 = by row length (3 from 16 steps on), 2 or 3
     bool opt_sync_sizes = false, opt_short_rerank = true;
     int64_t opt_projection_min_rows = 4096;           // batches of at least this many vectors hash on the matrix cores (0: never)
 };
@@ -272,7 +274,7 @@ extern "C" int dpf_create(const dpf_config *cfg, dpf_index **out)
     if (e == hipSuccess) e = hipMemset(ix->d_proj_counters, 0, 16);
     if (e == hipSuccess) e = hipHostMalloc((void **)&ix->pinned, 8 * sizeof(int64_t), hipHostMallocDefault);
     for (int i = 0; i < 6 && e == hipSuccess; i++) e = hipEventCreate(&ix->ev[i]);
-    for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipEventCreate(&ix->ev_scan[i]);
+    for (int i = 0; i < 6 && e == hipSuccess; i++) e = hipEventCreate(&ix->ev_scan[i]);
     if (e != hipSuccess) {
         std::string m = std::string("dpf_create: ") + hipGetErrorString(e);
         delete ix;
@@ -312,7 +314,7 @@ extern "C" void dpf_destroy(dpf_index *ix)
     { DevBuf *pb[] = {&ix->d_fn_norm, &ix->ws_proj_codes, &ix->ws_proj_norm, &ix->ws_proj_flag, &ix->ws_proj_rows}; for (DevBuf *b : pb) b->release(); }
     if (ix->pinned) (void)hipHostFree(ix->pinned);
     for (int i = 0; i < 6; i++) if (ix->ev[i]) (void)hipEventDestroy(ix->ev[i]);
-    for (int i = 0; i < 4; i++) if (ix->ev_scan[i]) (void)hipEventDestroy(ix->ev_scan[i]);
+    for (int i = 0; i < 6; i++) if (ix->ev_scan[i]) (void)hipEventDestroy(ix->ev_scan[i]);
     DevBuf *more[] = {&ix->ws_emit_ucnt, &ix->ws_emit_v, &ix->ws_leaf_units, &ix->ws_unit_off, &ix->ws_q_leaves, &ix->ws_q_leaf_cnt, &ix->d_leaf_tile0, &ix->ws_units, &ix->d_tiles, &ix->ws_lq_off, &ix->ws_lq_cursor, &ix->ws_leaf_queries,
                       &ix->ws_seed_cand, &ix->ws_seed_cnt, &ix->ws_seed_ids, &ix->ws_seed_scores, &ix->ws_emit, &ix->ws_emit_cnt,
                       &ix->d_base16, &ix->ws_q16, &ix->d_base16n, &ix->ws_q16n, &ix->d_base16e, &ix->ws_q16e, &ix->ws_flag, &ix->ws_tau, &ix->ws_qc, &ix->d_slot_norm, &ix->d_base16t, &ix->d_slot_tail, &ix->ws_q16t, &ix->ws_ovf, &ix->sub_q, &ix->sub_qids, &ix->sub_ids,
@@ -1051,7 +1053,8 @@ static void fill_rerank_params(dpf_index *ix, RerankParams &rp, const void *d_Qp
 // scan totals (incidences, units) as int64 at byte 16, and from byte 128 the ticket counters of the two scan
 // launches (each counter on a 128-byte line of its own)
 static const int TICKET_COUNTERS = 16;
-static const size_t FLAG_BYTES = 128 + 2 * (size_t)TICKET_COUNTERS * 128;
+static const int MAX_SCAN_PASSES = 3;
+static const size_t FLAG_BYTES = 128 + MAX_SCAN_PASSES * (size_t)TICKET_COUNTERS * 128;
 // the per-query forward counts sit behind them, so that one memset clears everything a batch starts from
 // Everything a batch starts from at zero sits in ONE buffer, cleared by one memset: the per-bucket incidence
 // histogram lq_cnt[num_leaves + 1] first (its size only changes with a fit), the flag block behind it.
@@ -1202,23 +1205,28 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     if (ix->filter_dim < ix->cfg.dim) { lp.slot_tail = (const uint4 *)ix->d_slot_tail.p; lp.q_tail = (const uint4 *)ix->ws_q16t.p; }
     lp.num_counters = TICKET_COUNTERS;
     lp.tickets = (unsigned int *)(flag_block_of(ix) + 128);
-    // a first slice of the units, then thresholds refined from what it forwarded, then the rest
+    // Slices of the units with the thresholds refined from what has been forwarded in between: a first tenth, then the
+    // rest; for long rows (one wave per SIMD: nothing hides the cost of a forwarded row) a fiftieth goes before them.
     const int first_permille = ix->opt_first_permille;
-    int64_t n_first = std::min<int64_t>(nunits, nunits * first_permille / 1000);
-    if (carried) { lp.totals = d_totals; lp.abort = flags + 3; lp.first_permille = first_permille; }
-    lp.pass = 0;
-    lp.unit_begin = 0; lp.unit_end = n_first;
-    if (ix->profiling) HIPCHECK(ix, hipEventRecord(ix->ev_scan[0], stream));
-    launch_leafscan(ix->cfg.metric, lp, stream);
-    if (ix->profiling) HIPCHECK(ix, hipEventRecord(ix->ev_scan[1], stream));
-    if (n_first > 0 || carried)
-        launch_refine(ix->cfg.metric, lp.emit, lp.emit_v, lp.emit_cnt, EMIT_CAP, k, nq, ix->ws_q16e.as<float>(), lp.tau, stream);
-    lp.pass = 1;
-    lp.unit_begin = n_first; lp.unit_end = nunits;
-    lp.tickets += TICKET_COUNTERS * 32;                   // the second launch's own counters
-    if (ix->profiling) HIPCHECK(ix, hipEventRecord(ix->ev_scan[2], stream));
-    launch_leafscan(ix->cfg.metric, lp, stream);
-    if (ix->profiling) HIPCHECK(ix, hipEventRecord(ix->ev_scan[3], stream));
+    const int passes = ix->opt_scan_passes ? ix->opt_scan_passes : (ix->ks16 >= 16 ? 3 : 2);
+    int cuts[MAX_SCAN_PASSES + 1], ncuts = 0;
+    cuts[ncuts++] = 0;
+    if (passes >= 3 && ix->opt_early_permille > 0 && ix->opt_early_permille < first_permille) cuts[ncuts++] = ix->opt_early_permille;
+    if (first_permille > 0 && first_permille < 1000) cuts[ncuts++] = first_permille;
+    cuts[ncuts++] = 1000;
+    if (carried) { lp.totals = d_totals; lp.abort = flags + 3; }
+    for (int e = 0; e < 6; e += 2) ix->ev_scan_used[e / 2] = false;
+    for (int s = 0; s + 1 < ncuts; s++) {
+        lp.permille_lo = cuts[s]; lp.permille_hi = cuts[s + 1];
+        lp.unit_begin = nunits * cuts[s] / 1000; lp.unit_end = nunits * cuts[s + 1] / 1000;
+        if (ix->profiling) HIPCHECK(ix, hipEventRecord(ix->ev_scan[2 * s], stream));
+        launch_leafscan(ix->cfg.metric, lp, stream);
+        if (ix->profiling) HIPCHECK(ix, hipEventRecord(ix->ev_scan[2 * s + 1], stream));
+        ix->ev_scan_used[s] = ix->profiling;
+        if (s + 2 < ncuts && (lp.unit_end > 0 || carried))
+            launch_refine(ix->cfg.metric, lp.emit, lp.emit_v, lp.emit_cnt, EMIT_CAP, k, nq, ix->ws_q16e.as<float>(), lp.tau, stream);
+        lp.tickets += TICKET_COUNTERS * 32;               // every launch has its own counters
+    }
     HIPCHECK(ix, ix->ws_ovf.ensure((size_t)nq * 4));
     // one small kernel lists the overflowed queries and writes the batch's 32-byte record (flags + totals) straight
     // into the pinned host words the host reads after the wait
@@ -1232,11 +1240,12 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
             return rc;
         }
         pairs = ix->pinned[6]; nunits = ix->pinned[7];
-        n_first = std::min<int64_t>(nunits, nunits * first_permille / 1000);
     }
     ix->st.last_sizes_carried = carried ? 1 : 0;
     ix->sizes_carried = !lists_truncated;
-    ix->scan_launches = n_first > 0 ? 2 : 1;
+    ix->scan_launches = 0;
+    for (int s2 = 0; s2 + 1 < ncuts; s2++) ix->scan_launches += nunits * cuts[s2 + 1] / 1000 > nunits * cuts[s2] / 1000 ? 1 : 0;
+    if (ix->scan_launches == 0) ix->scan_launches = 1;
     ix->st.last_pairs = pairs;
     // Queries whose forward list overflowed are answered by the gather path afterwards, as a batch of
     // their own; when they are many the whole batch goes that way.
@@ -1555,6 +1564,14 @@ extern "C" int dpf_set_option(dpf_index *ix, int32_t option, int64_t value)
         if (value < 0 || value > 1000) return fail(ix, DPF_EINVAL, "dpf_set_option: first-pass share must be in [0, 1000]");
         ix->opt_first_permille = (int32_t)value;
         return DPF_OK;
+    case DPF_OPT_SCAN_PASSES:
+        if (value != 0 && value != 2 && value != 3) return fail(ix, DPF_EINVAL, "dpf_set_option: scan passes must be 0 (by row length), 2 or 3");
+        ix->opt_scan_passes = (int32_t)value;
+        return DPF_OK;
+    case DPF_OPT_EARLY_PASS_PERMILLE:
+        if (value < 0 || value > 1000) return fail(ix, DPF_EINVAL, "dpf_set_option: early-pass share must be in [0, 1000]");
+        ix->opt_early_permille = (int32_t)value;
+        return DPF_OK;
     case DPF_OPT_SEED_SAMPLE:
         if (value < 16 || value > 4096) return fail(ix, DPF_EINVAL, "dpf_set_option: seed sample must be in [16, 4096]");
         ix->opt_seed_cap = (int32_t)value;
@@ -1622,9 +1639,15 @@ extern "C" int dpf_get_stats(dpf_index *ix, dpf_stats *out)
     if (ix->last_valid && ix->last_path == 1) {
         ix->st.last_forwarded = ix->st.last_unique_candidates;
         ix->st.last_unique_candidates = 0;          // the sets are not materialised on this path
-        float t = 0, t2 = 0;
-        if (ix->last_timed && hipEventElapsedTime(&t, ix->ev_scan[0], ix->ev_scan[1]) == hipSuccess &&
-            hipEventElapsedTime(&t2, ix->ev_scan[2], ix->ev_scan[3]) == hipSuccess) ix->st.last_ms_scan = t + t2;
+        float sum = 0;
+        bool ok = ix->last_timed;
+        for (int s2 = 0; s2 < 3 && ok; s2++) {
+            float t = 0;
+            if (!ix->ev_scan_used[s2]) continue;
+            ok = hipEventElapsedTime(&t, ix->ev_scan[2 * s2], ix->ev_scan[2 * s2 + 1]) == hipSuccess;
+            sum += t;
+        }
+        if (ok) ix->st.last_ms_scan = sum;
         ix->st.last_scan_launches = ix->scan_launches;
     }
     if (ix->last_timed && ix->last_valid) {
@@ -1654,10 +1677,12 @@ extern "C" int dpf_last_rerank_profile(dpf_index *ix, double *ms, int64_t *algor
     HIPCHECK(ix, hipEventSynchronize(ix->ev[5]));
     float t = 0;
     if (ix->last_path == 1) {
-        float t2 = 0;
-        HIPCHECK(ix, hipEventElapsedTime(&t, ix->ev_scan[0], ix->ev_scan[1]));
-        HIPCHECK(ix, hipEventElapsedTime(&t2, ix->ev_scan[2], ix->ev_scan[3]));
-        t += t2;
+        for (int s2 = 0; s2 < 3; s2++) {
+            float t2 = 0;
+            if (!ix->ev_scan_used[s2]) continue;
+            HIPCHECK(ix, hipEventElapsedTime(&t2, ix->ev_scan[2 * s2], ix->ev_scan[2 * s2 + 1]));
+            t += t2;
+        }
     } else {
         HIPCHECK(ix, hipEventElapsedTime(&t, ix->ev[4], ix->ev[5]));
     }

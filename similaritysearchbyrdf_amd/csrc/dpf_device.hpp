@@ -91,10 +91,10 @@ struct LeafScanParams {
     const uint4 *units;          // work units of the batch, see k_units
     int64_t unit_begin, unit_end; // the slice of units[] this launch works through ...
     // ... or, when the host has not read the batch's unit count (totals != nullptr): totals[1] units in all,
-    // pass 0 takes the first first_permille/1000 of them, pass 1 the rest; nothing when *abort is non-zero
+    // a launch takes a slice of them given in thousandths; nothing when *abort is non-zero
     const int64_t *totals = nullptr;
     const int32_t *abort = nullptr;
-    int32_t first_permille = 0, pass = 0;
+    int32_t permille_lo = 0, permille_hi = 0;   // the launch takes the units [totals[1] * lo / 1000, totals[1] * hi / 1000)
     int32_t num_cus;
     unsigned int *tickets;       // num_counters ticket counters of this launch, 32 words apart, zeroed
     int32_t num_counters;

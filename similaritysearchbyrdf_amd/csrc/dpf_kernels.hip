@@ -1490,9 +1490,9 @@ __global__ __launch_bounds__(256, ls16_waves(KS, RB)) void k_leafscan_f16(LeafSc
     uint32_t ubegin = (uint32_t)p.unit_begin, nunits = (uint32_t)p.unit_end;
     if (p.totals) {                                       // the slice comes from the device-side unit count
         if (*p.abort) return;
-        const int64_t all = p.totals[1], first = all * p.first_permille / 1000;
-        ubegin = p.pass ? (uint32_t)first : 0u;
-        nunits = p.pass ? (uint32_t)all : (uint32_t)first;
+        const int64_t all = p.totals[1];
+        ubegin = (uint32_t)(all * p.permille_lo / 1000);
+        nunits = (uint32_t)(all * p.permille_hi / 1000);
     }
     const uint32_t nc = (uint32_t)p.num_counters, cidx = blockIdx.x % nc;
     const uint32_t place = (blockIdx.x / nc) * 4u + (uint32_t)wave;

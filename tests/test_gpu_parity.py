@@ -993,3 +993,29 @@ def test_cut_rows_with_tails_filter_exactly(kind, dim, row_bytes):
     assert f_cut <= 1.3 * f_whole + 2 * nq, (f_cut, f_whole)
     for ix in (fast, full, slow):
         ix.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim,passes,early,first", [(100, 3, 40, 100), (100, 3, 300, 600), (100, 2, 0, 0), (100, 2, 0, 1000),
+                                                    (768, 2, 0, 100), (768, 3, 5, 10), (768, 3, 500, 999), (768, 0, 40, 100)])
+def test_scan_in_two_or_three_passes(dim, passes, early, first):
+    # the work units of the scan run in slices with the thresholds refined in between; however they are cut (no
+    # early slice, an empty first one, nearly everything before the last refinement), the answer is the gather path's
+    params, X, Q, pick = make_problem(n=12000, nq=150, dim=dim, bucket_overflow=60, table_num=3, permutation_num=2, n_clusters=8)
+    fast = DpfIndex(params, metric="l2")
+    slow = DpfIndex(dict(params, flags=2), metric="l2")
+    fast.fit(X)
+    slow.fit(X)
+    fast.set_option("scan_passes", passes)
+    fast.set_option("early_pass_permille", early)
+    fast.set_option("first_pass_permille", first)
+    si, ss = slow.query_topk(pick, Q, steps=1, k=10)
+    for rep in range(3):                                   # sized on the host, then twice with carried sizes
+        fi, fs = fast.query_topk(pick, Q, steps=1, k=10)
+        st = fast.stats()
+        assert st["last_path"] == 1 and st["last_sizes_carried"] == (0 if rep == 0 else 1)
+        assert np.array_equal(fi, si) and np.array_equal(fs, ss, equal_nan=True)
+    want = 1 + (1 if 0 < first < 1000 else 0) + (1 if (passes == 3 or (passes == 0 and dim >= 512)) and 0 < early < first else 0)
+    assert fast.stats()["last_scan_launches"] <= want
+    with pytest.raises(Exception):
+        fast.set_option("scan_passes", 4)
