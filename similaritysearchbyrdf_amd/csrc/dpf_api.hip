@@ -167,6 +167,7 @@ struct dpf_index {
     hipEvent_t ev_scan[6]{};                          // begin and end of up to three passes of the scan
     int scan_launches = 0;
     bool ev_scan_used[3] = {false, false, false};
+    int64_t prev_units = -1;                 // work units of the handle's last bucket-major batch (-1: none yet)
     unsigned long long *d_short_hash = nullptr;
     int64_t *pinned = nullptr;                        // host-pinned scratch (8 x int64)
     bool sizes_carried = false;                       // a bucket-major batch has sized leaf_queries[] / units[] already
@@ -1166,8 +1167,10 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
                        ix->ws_seed_ids.as<int32_t>(), ix->ws_seed_scores.as<double>());
     rp.cand_stride = SEED_CAP;
     const bool short_lists = ix->opt_short_rerank;
-    if (short_lists && rerank_short_applies(rp)) launch_rerank_short(ix->cfg.dtype, ix->cfg.metric, rp, nq, stream);
-    else launch_rerank(ix->cfg.dtype, ix->cfg.metric, rp, nq, stream);
+    if (SEED_CAP > 0) {
+        if (short_lists && rerank_short_applies(rp)) launch_rerank_short(ix->cfg.dtype, ix->cfg.metric, rp, nq, stream);
+        else launch_rerank(ix->cfg.dtype, ix->cfg.metric, rp, nq, stream);
+    }
 
     // fp16 copies of the queries, first thresholds, the work list, the scan
     HIPCHECK(ix, ix->ws_q16.ensure((size_t)nq * ix->ks16 * 32 * 2));
@@ -1176,7 +1179,8 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     HIPCHECK(ix, ix->ws_qc.ensure((size_t)nq * 16));
     {   // the conversion's last lane of every query row also writes the query's first threshold and scan record
         TauParams tp;
-        tp.metric = ix->cfg.metric; tp.seed_scores = ix->ws_seed_scores.as<double>(); tp.seed_ids = ix->ws_seed_ids.as<int32_t>();
+        tp.metric = ix->cfg.metric;
+        if (SEED_CAP > 0) { tp.seed_scores = ix->ws_seed_scores.as<double>(); tp.seed_ids = ix->ws_seed_ids.as<int32_t>(); }
         tp.k = k; tp.qids = d_qids; tp.tau = ix->ws_tau.as<int32_t>(); tp.qc = (float4 *)ix->ws_qc.p;
         const bool tails = ix->filter_dim < ix->cfg.dim;
         if (tails) HIPCHECK(ix, ix->ws_q16t.ensure((size_t)nq * 16));
@@ -1209,10 +1213,14 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     // rest; for long rows (one wave per SIMD: nothing hides the cost of a forwarded row) a fiftieth goes before them.
     const int first_permille = ix->opt_first_permille;
     const int passes = ix->opt_scan_passes ? ix->opt_scan_passes : (ix->ks16 >= 16 ? 3 : 2);
+    // A batch of few units (a single-table forest: a dozen units per wave) gains nothing from a refinement that costs
+    // two more launches: one slice.  Judged by this batch's count when the host has read it, by the last batch's otherwise.
+    const int64_t units_hint = carried ? ix->prev_units : nunits;
+    const bool tiny = ix->opt_scan_passes == 0 && units_hint >= 0 && units_hint < (int64_t)ix->num_cus * 12 * 16;
     int cuts[MAX_SCAN_PASSES + 1], ncuts = 0;
     cuts[ncuts++] = 0;
-    if (passes >= 3 && ix->opt_early_permille > 0 && ix->opt_early_permille < first_permille) cuts[ncuts++] = ix->opt_early_permille;
-    if (first_permille > 0 && first_permille < 1000) cuts[ncuts++] = first_permille;
+    if (!tiny && passes >= 3 && ix->opt_early_permille > 0 && ix->opt_early_permille < first_permille) cuts[ncuts++] = ix->opt_early_permille;
+    if (!tiny && first_permille > 0 && first_permille < 1000) cuts[ncuts++] = first_permille;
     cuts[ncuts++] = 1000;
     if (carried) { lp.totals = d_totals; lp.abort = flags + 3; }
     for (int e = 0; e < 6; e += 2) ix->ev_scan_used[e / 2] = false;
@@ -1247,6 +1255,7 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     for (int s2 = 0; s2 + 1 < ncuts; s2++) ix->scan_launches += nunits * cuts[s2 + 1] / 1000 > nunits * cuts[s2] / 1000 ? 1 : 0;
     if (ix->scan_launches == 0) ix->scan_launches = 1;
     ix->st.last_pairs = pairs;
+    ix->prev_units = nunits;
     // Queries whose forward list overflowed are answered by the gather path afterwards, as a batch of
     // their own; when they are many the whole batch goes that way.
     const int64_t n_ovf = (int32_t)(ix->pinned[4] & 0xffffffff);
@@ -1573,7 +1582,7 @@ extern "C" int dpf_set_option(dpf_index *ix, int32_t option, int64_t value)
         ix->opt_early_permille = (int32_t)value;
         return DPF_OK;
     case DPF_OPT_SEED_SAMPLE:
-        if (value < 16 || value > 4096) return fail(ix, DPF_EINVAL, "dpf_set_option: seed sample must be in [16, 4096]");
+        if (value != 0 && (value < 16 || value > 4096)) return fail(ix, DPF_EINVAL, "dpf_set_option: seed sample must be 0 (none) or in [16, 4096]");
         ix->opt_seed_cap = (int32_t)value;
         return DPF_OK;
     case DPF_OPT_SHORT_RERANK:

@@ -1713,8 +1713,9 @@ int leafscan_f16_filter_dim(int dim, int metric)
 // query with fewer than k seeds starts without a threshold.
 __device__ __forceinline__ void write_tau(const TauParams &t, int64_t q, float qn, float qe, int stride)
 {
-    const int32_t kth_id = t.seed_ids[q * t.k + t.k - 1];
-    const double kth = t.seed_scores[q * t.k + t.k - 1];
+    // (no seed sample: every query starts without a threshold)
+    const int32_t kth_id = t.seed_ids ? t.seed_ids[q * t.k + t.k - 1] : -1;
+    const double kth = t.seed_ids ? t.seed_scores[q * t.k + t.k - 1] : 0.0;
     const float c32 = leafscan_c32(stride);
     float v;
     if (t.metric == 1) v = kth_id < 0 ? HUGE_VALF : sqrtf(fmaxf((float)kth, 0.f) * 1.000001f) * 1.000001f + qe;
