@@ -1167,6 +1167,12 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
                        ix->ws_seed_ids.as<int32_t>(), ix->ws_seed_scores.as<double>());
     rp.cand_stride = SEED_CAP;
     const bool short_lists = ix->opt_short_rerank;
+    if (SEED_CAP > 0 && pp.t_end - pp.t_begin > 1) {
+        // a near neighbour sits in the query's own bucket of several tables: every id of the sample once
+        HIPCHECK(ix, ix->ws_emit_ucnt.ensure((size_t)nq * 4));
+        launch_unique_lists(ix->ws_seed_cand.as<int32_t>(), ix->ws_seed_cnt.as<int32_t>(), SEED_CAP, SEED_CAP, ix->ws_emit_ucnt.as<int32_t>(), nq, stream);
+        rp.cnt = ix->ws_emit_ucnt.as<int32_t>();
+    }
     if (SEED_CAP > 0) {
         if (short_lists && rerank_short_applies(rp)) launch_rerank_short(ix->cfg.dtype, ix->cfg.metric, rp, nq, stream);
         else launch_rerank(ix->cfg.dtype, ix->cfg.metric, rp, nq, stream);
