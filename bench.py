@@ -153,7 +153,7 @@ def roofline_of(ix, run_batch, nbatches, repeats, n, nq, world, workload_name, s
         tot_bytes += by
         launches_total += launches
     ix.set_profiling(False)
-    kernel = "k_leafscan_f16" if st["last_path"] == 1 else "k_rerank"
+    kernel = "k_rerank" if st["last_path"] != 1 else "k_leafscan_i8" if st["last_scan_int8"] == 1 else "k_leafscan_f16"
     rr = tot_ms / launches_total
     rr_bytes = tot_bytes / launches_total
     achieved = rr_bytes / (rr * 1e-3) / 1e9
@@ -163,11 +163,13 @@ def roofline_of(ix, run_batch, nbatches, repeats, n, nq, world, workload_name, s
            "algorithmic_bytes_per_launch": rr_bytes, "ms_per_launch": rr,
            "launches_per_batch": launches_total / float(repeats * nbatches)}
     if st["last_path"] == 1:
-        table_mb = st["base16_bytes"] / 1e6
-        out["bound_note"] = ("bytes cross the L2 <-> Infinity Fabric boundary; the fp16 table the scan re-reads is %.0f MB "
+        int8 = st["last_scan_int8"] == 1
+        table_mb = (st["base8_bytes"] if int8 else st["base16_bytes"]) / 1e6
+        out["bound_note"] = ("bytes cross the L2 <-> Infinity Fabric boundary; the %s table the scan re-reads is %.0f MB "
                              "against 256 MiB of Infinity Cache, so %s of these bytes can be served from that cache rather "
-                             "than from HBM" % (table_mb, "most" if table_mb <= 270 else "only a fraction"))
-        out["fp16_table_mb"] = table_mb
+                             "than from HBM" % ("int8" if int8 else "fp16", table_mb, "most" if table_mb <= 270 else "only a fraction"))
+        out["scan_arithmetic"] = "int8 products, int32 sums (v_mfma_i32_16x16x64_i8)" if int8 else "fp16 products, fp32 sums (v_mfma_f32_16x16x32_f16)"
+        out["int8_table_mb" if int8 else "fp16_table_mb"] = table_mb
         out["tile_rows"] = st["tile_rows"]
         out["mean_tile_occupancy"] = st["resident_ids"] / float(max(1, st["num_tiles"]) * max(1, st["tile_rows"]))
     if rec:
@@ -200,6 +202,8 @@ def main():
                     help="dpf_set_option on the handle before the batches, e.g. --option scan_passes=3 (repeatable)")
     ap.add_argument("--full-filter", action="store_true",
                     help="fp16 copies of every dimension (DPF_FLAG_FULL_FILTER) instead of the leading ones: A/B of the truncated filter")
+    ap.add_argument("--no-int8", action="store_true",
+                    help="never scan in int8 (DPF_FLAG_NO_INT8): A/B of the exact integer scan on integer-valued bases (c4)")
     ap.add_argument("--large-table-rows", type=int, default=4_000_000,
                     help="c3 on one GPU: base rows of the extra roofline run whose fp16 table (256 B per row) is several "
                          "times the Infinity Cache; 0 = skip")
@@ -239,6 +243,8 @@ def main():
         params["flags"] = 2          # DPF_FLAG_GATHER_ONLY
     if args.full_filter:
         params["flags"] = int(params.get("flags", 0)) | 8          # DPF_FLAG_FULL_FILTER
+    if args.no_int8:
+        params["flags"] = int(params.get("flags", 0)) | 16         # DPF_FLAG_NO_INT8
     if args.search_steps is not None:
         steps = args.search_steps
     n, nq, k = X.shape[0], Q.shape[0], args.k
@@ -444,7 +450,10 @@ def main():
                                        args.workload, X.shape[1], n, nq, ix.L, ix.pb, params["bucket_overflow"],
                                        steps, k, args.metric),
                        "arithmetic": "rows and queries float32 in HBM; hashing and the exact rerank in float64; "
-                                     "the bucket-major filter in fp16 products with fp32 accumulation (matrix cores)",
+                                     "the bucket-major filter in " + (
+                                         "int8 products with int32 accumulation (matrix cores; rows and queries are integers "
+                                         "inside one window of 256 values)" if st["last_scan_int8"] == 1 else
+                                         "fp16 products with fp32 accumulation (matrix cores)"),
                        "global_batch": nq, "distinct_batches_in_timed_loop": nb,
                        "parallelism": "one GPU" if world == 1 else ("%s: %d query groups x %d %s groups" % (
                            sharded.mode, sharded.qg, sharded.sg, "table" if sharded.mode == "tables" else "row")),
@@ -453,7 +462,8 @@ def main():
                        "fit_seconds": round(fit_s, 3),
                        "fit_ms_on_rank0": {"copy_in_and_hash": round(st["fit_ms_hash"], 1),
                                            "forest_build_on_device": round(st["fit_ms_forest"], 1)},
-                       "rerank_path": "bucket-major fp16 scan + exact fp64 rerank" if st["last_path"] == 1 else "gather",
+                       "rerank_path": ("bucket-major %s scan + exact fp64 rerank" % ("int8" if st["last_scan_int8"] == 1 else "fp16"))
+                                      if st["last_path"] == 1 else "gather",
                        "ids_visited_per_query_on_rank0": st["last_raw_candidates"] / nq,
                        "unique_candidates_per_query_on_rank0": (st["last_unique_candidates"] / nq) if st["last_path"] == 0 else None,
                        "bucket_incidences_per_query_on_rank0": st["last_pairs"] / nq,

@@ -58,7 +58,12 @@ enum { DPF_FLAG_HASH_ONLY = 1,
  * dimension exceeds a row length the scan has a kernel for by at most 8 (and at most a sixteenth: 100 -> 96,
  * 136 -> 128, 260 -> 256, ...) scan rows cut there and put the remaining dimensions' share back for the scores that
  * pass: the same filter in two stages, same results, fewer bytes per scanned row (the flag is for A/B). */
-       DPF_FLAG_FULL_FILTER = 8 };
+       DPF_FLAG_FULL_FILTER = 8,
+/* DPF_FLAG_NO_INT8: never scan in int8.  Without it an l2 handle of up to 256 dimensions whose resident rows are all
+ * integer-valued inside one window of 256 values (SIFT's 0..255) keeps an int8 copy of them beside the fp16 one, and a
+ * batch whose queries fit the window too is scanned with exact integer products on half the bytes (same results;
+ * other batches take the fp16 scan; the flag is for A/B). */
+       DPF_FLAG_NO_INT8 = 16 };
 
 /* The subset of the reference's Typesafe-Config keys the path consumes
  * (TestSettings.scala:8-45; read at LSH:19-33, Dense:39-58). */
@@ -132,6 +137,8 @@ typedef struct dpf_stats {
     int64_t resident_ids;            /* bucket entries (id, table) of this handle's row / table shard            */
     int64_t hash_undecided_rows;     /* since dpf_create: vectors whose matrix-core projection fell inside the guard band
                                         of some function and were hashed again by the exact kernel                       */
+    int64_t base8_bytes;             /* HBM bytes of the int8 copy of the resident rows (0: the rows do not allow one)   */
+    int64_t last_scan_int8;          /* 1: the last bucket-major batch was scanned in int8, 0: in fp16                    */
 } dpf_stats;
 
 typedef struct dpf_index dpf_index;

@@ -150,6 +150,14 @@ struct dpf_index {
     int32_t emit_cap = 8192;                 // entries per forward list
     DevBuf sub_q, sub_qids, sub_ids, sub_scores, sub_ws[6];   // their batch on the gather path
     DevBuf d_base16, ws_q16;                 // fp16 copies of the resident rows / of the query batch
+    // int8 form of the scan: kept beside the fp16 copy when every resident row is integer-valued inside one window of
+    // 256 values (l2 handles, rows of up to 256 dimensions); a batch whose queries fit the window too is scanned in int8
+    DevBuf d_base8, d_norm8, d_slot_nj8, d_i8_probe;   // rows minus the window's centre, their |x'|^2, -floor(|x'|^2 / 2) in bucket order
+    DevBuf ws_q8, ws_qc8;                    // the query batch's int8 rows and scan records
+    bool i8_ok = false;
+    int ks8 = 0;                             // 64-byte steps per int8 row
+    float i8_offset = 0.f;                   // the window's centre
+    bool last_scan_int8 = false;
     int ks16 = -1;                           // 32-dimension fp16 steps per padded row (-1: no fp16 scan)
     int filter_dim = 0;                      // dimensions the fp16 rows keep; the rest (at most 8) travels as 16-byte tails
     int64_t ntiles = 0, nutiles = 0, num_leaves = 0;
@@ -169,7 +177,7 @@ struct dpf_index {
     bool ev_scan_used[3] = {false, false, false};
     int64_t prev_units = -1;                 // work units of the handle's last bucket-major batch (-1: none yet)
     unsigned long long *d_short_hash = nullptr;
-    int64_t *pinned = nullptr;                        // host-pinned scratch (8 x int64)
+    int64_t *pinned = nullptr;                        // host-pinned scratch (12 x int64)
     bool sizes_carried = false;                       // a bucket-major batch has sized leaf_queries[] / units[] already
     hipEvent_t ev[6]{};
     int last_path = 0;
@@ -273,7 +281,7 @@ extern "C" int dpf_create(const dpf_config *cfg, dpf_index **out)
     if (e == hipSuccess) e = hipMemset(ix->d_short_hash, 0, sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc((void **)&ix->d_proj_counters, 16);
     if (e == hipSuccess) e = hipMemset(ix->d_proj_counters, 0, 16);
-    if (e == hipSuccess) e = hipHostMalloc((void **)&ix->pinned, 8 * sizeof(int64_t), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&ix->pinned, 12 * sizeof(int64_t), hipHostMallocDefault);
     for (int i = 0; i < 6 && e == hipSuccess; i++) e = hipEventCreate(&ix->ev[i]);
     for (int i = 0; i < 6 && e == hipSuccess; i++) e = hipEventCreate(&ix->ev_scan[i]);
     if (e != hipSuccess) {
@@ -318,7 +326,7 @@ extern "C" void dpf_destroy(dpf_index *ix)
     for (int i = 0; i < 6; i++) if (ix->ev_scan[i]) (void)hipEventDestroy(ix->ev_scan[i]);
     DevBuf *more[] = {&ix->ws_emit_ucnt, &ix->ws_emit_v, &ix->ws_leaf_units, &ix->ws_unit_off, &ix->ws_q_leaves, &ix->ws_q_leaf_cnt, &ix->d_leaf_tile0, &ix->ws_units, &ix->d_tiles, &ix->ws_lq_off, &ix->ws_lq_cursor, &ix->ws_leaf_queries,
                       &ix->ws_seed_cand, &ix->ws_seed_cnt, &ix->ws_seed_ids, &ix->ws_seed_scores, &ix->ws_emit, &ix->ws_emit_cnt,
-                      &ix->d_base16, &ix->ws_q16, &ix->d_base16n, &ix->ws_q16n, &ix->d_base16e, &ix->ws_q16e, &ix->ws_flag, &ix->ws_tau, &ix->ws_qc, &ix->d_slot_norm, &ix->d_base16t, &ix->d_slot_tail, &ix->ws_q16t, &ix->ws_ovf, &ix->sub_q, &ix->sub_qids, &ix->sub_ids,
+                      &ix->d_base16, &ix->ws_q16, &ix->d_base16n, &ix->ws_q16n, &ix->d_base16e, &ix->ws_q16e, &ix->ws_flag, &ix->ws_tau, &ix->ws_qc, &ix->d_slot_norm, &ix->d_base16t, &ix->d_slot_tail, &ix->ws_q16t, &ix->ws_ovf, &ix->d_base8, &ix->d_norm8, &ix->d_slot_nj8, &ix->d_i8_probe, &ix->ws_q8, &ix->ws_qc8, &ix->sub_q, &ix->sub_qids, &ix->sub_ids,
                       &ix->sub_scores, &ix->sub_ws[0], &ix->sub_ws[1], &ix->sub_ws[2], &ix->sub_ws[3], &ix->sub_ws[4], &ix->sub_ws[5]};
     for (DevBuf *b : more) b->release();
     delete ix;
@@ -512,6 +520,11 @@ static int upload_snapshot(dpf_index *ix, ForestSnapshot &s)
         launch_tile_maxnorm((uint4 *)ix->d_tiles.p, ix->nutiles, ix->d_ids.as<int32_t>(), ix->d_base16n.as<float>(), ix->d_base16e.as<float>(),
                             ix->row_begin, ix->row_begin + ix->base_rows, ix->d_slot_norm.as<float>(), nullptr,
                             tails ? (const uint4 *)ix->d_base16t.p : nullptr, tails ? (uint4 *)ix->d_slot_tail.p : nullptr);
+        if (ix->i8_ok) {
+            HIPCHECK(ix, ix->d_slot_nj8.ensure(std::max<size_t>(s.ids.size() * 4, 16)));
+            launch_slot_nj8(ix->d_ids.as<int32_t>(), (int64_t)s.ids.size(), ix->d_norm8.as<int32_t>(), ix->row_begin,
+                            ix->row_begin + ix->base_rows, ix->d_slot_nj8.as<int32_t>(), nullptr);
+        }
         HIPCHECK(ix, hipDeviceSynchronize());
     }
     return DPF_OK;
@@ -556,6 +569,7 @@ static int device_snapshot(dpf_index *ix, int64_t total)
     ix->d_dnodes.adopt(f.dnodes, (size_t)(f.num_dnodes + 1) * ix->geo.dir_node_size * 4);
     ix->d_leaf_off.adopt(f.leaf_off, ((size_t)f.num_leaves + 1) * 4);
     ix->d_ids.adopt(f.ids, std::max<size_t>((size_t)f.num_ids * 4, 16));
+    const int64_t num_ids = f.num_ids;
     f.roots = f.dnodes = f.leaf_off = nullptr;
     f.ids = nullptr;
     ix->d_leaf_tile0.adopt(lt0, ((size_t)f.num_leaves + 1) * 4 + 16);
@@ -580,6 +594,11 @@ static int device_snapshot(dpf_index *ix, int64_t total)
         launch_tile_maxnorm((uint4 *)ix->d_tiles.p, ix->nutiles, ix->d_ids.as<int32_t>(), ix->d_base16n.as<float>(), ix->d_base16e.as<float>(),
                             ix->row_begin, ix->row_begin + ix->base_rows, ix->d_slot_norm.as<float>(), nullptr,
                             tails ? (const uint4 *)ix->d_base16t.p : nullptr, tails ? (uint4 *)ix->d_slot_tail.p : nullptr);
+        if (ix->i8_ok) {
+            HIPCHECK(ix, ix->d_slot_nj8.ensure(std::max<size_t>((size_t)num_ids * 4, 16)));
+            launch_slot_nj8(ix->d_ids.as<int32_t>(), num_ids, ix->d_norm8.as<int32_t>(), ix->row_begin,
+                            ix->row_begin + ix->base_rows, ix->d_slot_nj8.as<int32_t>(), nullptr);
+        }
         HIPCHECK(ix, hipDeviceSynchronize());
     }
     return DPF_OK;
@@ -600,6 +619,29 @@ static int finish_fit(dpf_index *ix, int64_t total, int64_t new_rows)
         if (tails) HIPCHECK(ix, ix->d_base16t.ensure((size_t)new_rows * 16));
         launch_rows_to_f16(ix->d_base.as<float>(), ix->dpad, std::min(d, ix->filter_dim), new_rows, ix->d_base16.as<uint16_t>(), ix->ks16 * 32,
                             ix->d_base16n.as<float>(), ix->d_base16e.as<float>(), nullptr, nullptr, d, tails ? (uint4 *)ix->d_base16t.p : nullptr);
+    }
+    // The int8 copy, when the resident rows allow it: every value an integer, all of them inside one window of 256
+    // values (SIFT's 0..255, for one); the window's centre is subtracted, which leaves distances as they are.
+    ix->i8_ok = false;
+    if (ix->bucket_major && ix->ks16 > 0 && new_rows > 0 && ix->cfg.metric == DPF_METRIC_L2 && d <= 256 && !(ix->cfg.flags & DPF_FLAG_NO_INT8)) {
+        const int32_t init[4] = {INT32_MAX, INT32_MIN, 0, 0};
+        int32_t got[4];
+        HIPCHECK(ix, ix->d_i8_probe.ensure(16));
+        HIPCHECK(ix, hipMemcpy(ix->d_i8_probe.p, init, 16, hipMemcpyHostToDevice));
+        launch_i8_range(ix->d_base.as<float>(), ix->dpad, d, new_rows, ix->d_i8_probe.as<int32_t>(), nullptr);
+        HIPCHECK(ix, hipMemcpy(got, ix->d_i8_probe.p, 16, hipMemcpyDeviceToHost));
+        auto dec = [](int32_t b2) { b2 = b2 >= 0 ? b2 : (b2 ^ 0x7fffffff); float f; memcpy(&f, &b2, 4); return f; };
+        const float lo = dec(got[0]), hi = dec(got[1]);
+        if (got[2] == 0 && std::isfinite(lo) && std::isfinite(hi) && hi - lo <= 255.0f && std::fabs(lo) <= 1.0e6f && std::fabs(hi) <= 1.0e6f) {
+            ix->ks8 = (d + 63) / 64;
+            ix->i8_offset = lo + 128.0f;
+            HIPCHECK(ix, ix->d_base8.ensure((size_t)new_rows * ix->ks8 * 64));
+            HIPCHECK(ix, ix->d_norm8.ensure((size_t)new_rows * 4));
+            launch_rows_to_i8(ix->d_base.as<float>(), ix->dpad, d, new_rows, ix->i8_offset, ix->d_base8.as<int8_t>(), ix->ks8 * 64,
+                              ix->d_norm8.as<int32_t>(), nullptr, nullptr, ix->d_i8_probe.as<int32_t>() + 3, nullptr);
+            HIPCHECK(ix, hipMemcpy(got, ix->d_i8_probe.p, 16, hipMemcpyDeviceToHost));
+            ix->i8_ok = got[3] == 0;
+        }
     }
     HIPCHECK(ix, hipDeviceSynchronize());
     ix->base_rows = new_rows;
@@ -1193,6 +1235,15 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
         launch_rows_to_f16((const float *)qpad, ix->dpad, std::min(ix->cfg.dim, ix->filter_dim), nq, ix->ws_q16.as<uint16_t>(), ix->ks16 * 32,
                            ix->ws_q16n.as<float>(), ix->ws_q16e.as<float>(), stream, &tp, ix->cfg.dim, tails ? (uint4 *)ix->ws_q16t.p : nullptr);
     }
+    // int8 rows of the queries where the index has an int8 copy; flags[8] is raised when a query does not fit its window
+    int32_t *const i8_gate = flags + 8;
+    const bool i8 = ix->i8_ok && ix->d_slot_nj8.p != nullptr;
+    if (i8) {
+        HIPCHECK(ix, ix->ws_q8.ensure((size_t)nq * ix->ks8 * 64));
+        HIPCHECK(ix, ix->ws_qc8.ensure((size_t)nq * 16));
+        launch_rows_to_i8((const float *)qpad, ix->dpad, ix->cfg.dim, nq, ix->i8_offset, ix->ws_q8.as<int8_t>(), ix->ks8 * 64, nullptr,
+                          (float4 *)ix->ws_qc8.p, d_qids, i8_gate, stream);
+    }
     if (!carried) HIPCHECK(ix, ix->ws_units.ensure((size_t)std::max<int64_t>(nunits + nunits / 2, 1024) * 16));
     launch_units(lq_cnt_of(ix), ix->ws_lq_off.as<int64_t>(), ix->d_leaf_tile0.as<uint32_t>(),
                  (const uint4 *)ix->d_tiles.p, ix->nutiles, ix->ws_unit_off.as<int64_t>(), (uint4 *)ix->ws_units.p,
@@ -1234,6 +1285,17 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
         lp.permille_lo = cuts[s]; lp.permille_hi = cuts[s + 1];
         lp.unit_begin = nunits * cuts[s] / 1000; lp.unit_end = nunits * cuts[s + 1] / 1000;
         if (ix->profiling) HIPCHECK(ix, hipEventRecord(ix->ev_scan[2 * s], stream));
+        if (i8) {
+            // both forms of the slice are enqueued; the word the query conversion wrote lets one of them run
+            LeafScanParams l8 = lp;
+            l8.i8 = 1; l8.ks = ix->ks8;
+            l8.Q16 = (const uint16_t *)ix->ws_q8.p; l8.base16 = (const uint16_t *)ix->d_base8.p;
+            l8.qc = (const float4 *)ix->ws_qc8.p; l8.slot_nj8 = ix->d_slot_nj8.as<int32_t>();
+            l8.slot_tail = nullptr; l8.q_tail = nullptr;
+            l8.gate = i8_gate; l8.gate_want = 0;
+            launch_leafscan(ix->cfg.metric, l8, stream);
+            lp.gate = i8_gate; lp.gate_want = 1;
+        }
         launch_leafscan(ix->cfg.metric, lp, stream);
         if (ix->profiling) HIPCHECK(ix, hipEventRecord(ix->ev_scan[2 * s + 1], stream));
         ix->ev_scan_used[s] = ix->profiling;
@@ -1256,6 +1318,7 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
         pairs = ix->pinned[6]; nunits = ix->pinned[7];
     }
     ix->st.last_sizes_carried = carried ? 1 : 0;
+    ix->last_scan_int8 = i8 && (int32_t)(ix->pinned[8] & 0xffffffff) == 0;
     ix->sizes_carried = !lists_truncated;
     ix->scan_launches = 0;
     for (int s2 = 0; s2 + 1 < ncuts; s2++) ix->scan_launches += nunits * cuts[s2 + 1] / 1000 > nunits * cuts[s2] / 1000 ? 1 : 0;
@@ -1675,6 +1738,8 @@ extern "C" int dpf_get_stats(dpf_index *ix, dpf_stats *out)
         (void)hipGetLastError();      // an unrecorded event is not an error of this call
     }
     ix->st.base16_bytes = ix->bucket_major && ix->ks16 > 0 ? ix->base_rows * (int64_t)ix->ks16 * 64 : 0;
+    ix->st.base8_bytes = ix->i8_ok ? ix->base_rows * (int64_t)ix->ks8 * 64 : 0;
+    ix->st.last_scan_int8 = ix->last_valid && ix->last_path == 1 && ix->last_scan_int8 ? 1 : 0;
     ix->st.tile_rows = ix->bucket_major && ix->ks16 > 0 ? leafscan_tile_rows(ix->ks16) : 0;
     ix->st.num_tiles = ix->ntiles;
     ix->st.resident_ids = 0;
@@ -1715,8 +1780,8 @@ extern "C" int dpf_last_rerank_profile(dpf_index *ix, double *ms, int64_t *algor
         int64_t touched_rows = 0;
         for (size_t l = 0; l < c.size(); l++)
             if (c[l]) touched_rows += ix->h_leaf_len[l];
-        const int64_t srow = (int64_t)ix->ks16 * 64;
-        const int64_t tail = ix->filter_dim < ix->cfg.dim ? 16 : 0;        // the 16-byte tails of cut rows and query rows
+        const int64_t srow = ix->last_scan_int8 ? (int64_t)ix->ks8 * 64 : (int64_t)ix->ks16 * 64;
+        const int64_t tail = !ix->last_scan_int8 && ix->filter_dim < ix->cfg.dim ? 16 : 0;   // the 16-byte tails of cut rows and query rows
         if (algorithmic_bytes) *algorithmic_bytes = touched_rows * (srow + 8 + tail) + ix->st.last_pairs * (srow + 24 + tail) + uniq * 8;
         return DPF_OK;
     }

@@ -103,6 +103,15 @@ struct LeafScanParams {
     // cut, fp16, zero padded - the tile's in bucket order beside ids[], the queries' by query; nullptr: whole rows
     const uint4 *slot_tail = nullptr;
     const uint4 *q_tail = nullptr;
+    // int8 scan (l2, integer-valued rows and queries inside one window of 256 values): Q16 / base16 then point at
+    // int8 rows of ks * 64 bytes (values minus the window's centre), qc holds the shifted queries' records and
+    // slot_nj8[] = -floor(|x'|^2 / 2) of the shifted rows in bucket order beside ids[]
+    int32_t i8 = 0;
+    const int32_t *slot_nj8 = nullptr;
+    // a launch runs only when (*gate != 0) == (gate_want != 0) (gate == nullptr: always): the int8 and the fp16
+    // kernel of one slice are both enqueued and the word the query conversion wrote picks one
+    const int32_t *gate = nullptr;
+    int32_t gate_want = 0;
 };
 
 struct RerankParams {
@@ -172,11 +181,21 @@ struct TauParams {
 void launch_rows_to_f16(const float *src, int64_t src_stride, int dim, int64_t n, uint16_t *dst, int dst_stride,
                          float *norms, float *errs, hipStream_t stream, const TauParams *tau = nullptr, int dim_all = 0,
                          uint4 *tails = nullptr);
+// int8 copies for the exact integer scan.  launch_i8_range: out[0] = smallest value (order-preserving int image of the
+// float), out[1] = largest, out[2] != 0 when a value is no integer (out[] preset to INT32_MAX, INT32_MIN, 0).
+// launch_rows_to_i8: dst rows of dst_stride bytes (a multiple of 64) = value - offset, zero padded; *bad is raised when a
+// value minus the offset is no integer in [-128, 127]; base rows (qc == nullptr) leave |x'|^2 in norm2[r], query rows the
+// scan's record {|q'|^2 / 2, 0, |q'|^2, query id} in qc[r].  launch_slot_nj8: -floor(norm2 / 2) in bucket order.
+void launch_i8_range(const float *src, int64_t src_stride, int dim, int64_t n, int32_t *out, hipStream_t stream);
+void launch_rows_to_i8(const float *src, int64_t src_stride, int dim, int64_t n, float offset, int8_t *dst, int dst_stride,
+                       int32_t *norm2, float4 *qc, const int32_t *qids, int32_t *bad, hipStream_t stream);
+void launch_slot_nj8(const int32_t *ids, int64_t nslots, const int32_t *norm2, int64_t row_begin, int64_t row_end,
+                     int32_t *slot_nj8, hipStream_t stream);
 size_t unique_lists_lds(int32_t longest);
 void launch_unique_lists(int32_t *emit, const int32_t *emit_cnt, int32_t cap, int32_t longest, int32_t *unique_cnt, int64_t nq,
                          hipStream_t stream);
-// flag[0] = overflowed lists (their queries in list[]), flag[2] = longest list; then the 32 bytes at `flag` (flags and
-// the two scan totals) are copied to host_record (pinned host memory)
+// flag[0] = overflowed lists (their queries in list[]), flag[2] = longest list; then the 40 bytes at `flag` (flags,
+// the two scan totals and the int8 gate word) are copied to host_record (pinned host memory)
 void launch_overflow_list(const int32_t *emit_cnt, int64_t nq, int32_t cap, int32_t *flag, int32_t *list, int32_t *host_record,
                           hipStream_t stream);
 void launch_gather_queries(const int32_t *list, int64_t n, const void *Q, int64_t row_bytes, const int32_t *qids, void *subQ,

@@ -996,6 +996,19 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // threshold,   s - slack32 <= (sqrt(tau) + eta)^2 .
 // What is forwarded is rescored in fp64 from the fp32 rows.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// The int8 form of the scan (I8): rows and queries whose values are all integers inside one window of 256 values are
+// kept as int8 (value minus the window's centre; the distance does not change), 64 bytes per step of
+// v_mfma_i32_16x16x64_i8.  Products and sums are exact, so the filter needs no error terms: the accumulator starts at
+// -floor(|x'|^2 / 2) and delivers d_int = q'.x' - floor(|x'|^2 / 2), which is the exact d = q'.x' - |x'|^2 / 2 or half
+// a unit above it; the test d_int >= ceil(G) therefore lets through every row the exact test would, and
+// |q'|^2 - 2 d_int + 1 bounds the squared distance from above.  Half the bytes per row and per query row of the fp16
+// form, same tiles, units, thresholds and forward lists.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+template <bool I8> struct ScanTypes { typedef f32x4 acc4; typedef float val; };
+template <> struct ScanTypes<true> { typedef i32x4 acc4; typedef int32_t val; };
+static constexpr int32_t I8_ABSENT = -(1 << 29);       // accumulator start of a row the tile does not have
+static constexpr int32_t I8_NEVER = 1 << 29;           // threshold of a query slot that holds no query
+static constexpr float I8_G_FLOOR = -268435456.0f;     // thresholds are kept above -2^28: every present row passes, no absent one
 
 // Work units of one batch.  A unit is one 64-row tile of a touched bucket against at most
 // UNIT_QUERIES of the queries that probe the bucket: {first id slot, rows | queries << 8, first
@@ -1197,6 +1210,14 @@ __device__ __forceinline__ float best_of(const f32x4 (&acc)[RB], int r)
     for (int rb = 1; rb < RB; rb++) m = fmaxf(m, acc[rb][r]);
     return m;
 }
+template <int RB>
+__device__ __forceinline__ int32_t best_of(const i32x4 (&acc)[RB], int r)
+{
+    int32_t m = acc[0][r];
+#pragma unroll
+    for (int rb = 1; rb < RB; rb++) m = max(m, acc[rb][r]);
+    return m;
+}
 
 // 16-byte tails (8 fp16 values, see leafscan_f16_filter_dim): inner product in fp32 (exact products)
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
@@ -1232,15 +1253,18 @@ __device__ __forceinline__ float tail_dot(const uint4 &a, const uint4 &b)
 // at most a few fp32 ulps of |q_t|^2 + |x_t|^2, is covered by the slack 2e-6 (|q_t|^2 + |x_t|^2)) is put back:
 // d - t2_lo / 2 is the d of the whole fp16 rows (rounded towards keeping the row), s_hi + t2_hi their squared
 // distance from above.  Norms in the thresholds are the cut vectors', rounding distances the whole rows'.
-template <int KS, int METRIC, int RB, bool TAIL>
+template <int KS, int METRIC, int RB, bool TAIL, bool I8>
 __device__ __forceinline__ void leafscan_chunks(const LeafScanParams &p, const uint16_t *__restrict__ Q16, const f16x8 (&xb)[RB][KS],
-                                                const float (&nJ)[RB], const int32_t (&idj)[RB], uint32_t rows, uint32_t nq,
+                                                const typename ScanTypes<I8>::val (&nJ)[RB], const int32_t (&idj)[RB], uint32_t rows, uint32_t nq,
                                                 uint32_t lq0, float xrm, float cxm, int32_t qsc, int32_t qsn, int32_t *s_fq,
                                                 int32_t *s_fid, float *s_fv, float4 *s_slot, float *s_G, int32_t *s_qid, int &nbuf,
                                                 const uint4 *s_xt, uint4 *s_qt, float *s_qt2)
 {
     static_assert(!TAIL || METRIC == 1, "tails belong to the l2 filter");
     static_assert(RB == 4 || RB == 1, "64-row tiles, or 16-row tiles for rows of more than 768 dimensions");
+    static_assert(!I8 || (METRIC == 1 && RB == 4 && !TAIL && KS <= 4), "the int8 scan: l2, 64-row tiles, rows of up to 256 bytes");
+    typedef typename ScanTypes<I8>::acc4 acc4;
+    typedef typename ScanTypes<I8>::val val;
     // Rows of more than 8 steps: a 64-row tile still pays (one wave per SIMD holds it in the 512 registers
     // of its lanes; sharing a tile's rows among 4x the queries outweighs the lost occupancy: 1.4-1.5x
     // faster than 16-row tiles at 512 and 768 dimensions); beyond 24 steps only 16 rows fit (RB == 1).
@@ -1251,7 +1275,7 @@ __device__ __forceinline__ void leafscan_chunks(const LeafScanParams &p, const u
     const int i16 = lane & 15, g = lane >> 4;
     const uint32_t jq = 4u * (uint32_t)(i16 & 3) + (uint32_t)(i16 >> 2);   // chunk position of this lane's MFMA row
     constexpr int STRIDE = KS * 32;                       // fp16 elements per padded row
-    const float c32 = leafscan_c32(STRIDE);
+    const float c32 = I8 ? 0.f : leafscan_c32(STRIDE);
     auto flush = [&](int n) {
         if (lane < n) {
             const int32_t fq = s_fq[lane];
@@ -1293,14 +1317,24 @@ __device__ __forceinline__ void leafscan_chunks(const LeafScanParams &p, const u
                 }
             }
             if (g == 0) {
-                s_G[i16] = G;
+                if constexpr (I8) s_G[i16] = __int_as_float(qcur >= 0 ? (int32_t)ceilf(fmaxf(G, I8_G_FLOOR)) : I8_NEVER);
+                else s_G[i16] = G;
                 s_slot[i16] = make_float4(G2, __int_as_float(qcur), aux, qc.z);
                 s_qid[i16] = __float_as_int(qc.w);
                 if (TAIL) { s_qt[i16] = qtv; s_qt2[i16] = tail_dot(qtv, qtv); }
             }
         }
-        f32x4 acc[RB];
-        if constexpr (KS == QS) {
+        acc4 acc[RB];
+        if constexpr (I8) {
+#pragma unroll
+            for (int rb = 0; rb < RB; rb++) {
+                acc[rb] = (i32x4){nJ[rb], nJ[rb], nJ[rb], nJ[rb]};
+                if (rb * 16u >= rows && rb > 0) continue;
+#pragma unroll
+                for (int t = 0; t < KS; t++)
+                    acc[rb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, qa[t]), __builtin_bit_cast(i32x4, xb[rb][t]), acc[rb], 0, 0, 0);
+            }
+        } else if constexpr (KS == QS) {
 #pragma unroll
             for (int rb = 0; rb < RB; rb++) {
                 acc[rb] = (f32x4){nJ[rb], nJ[rb], nJ[rb], nJ[rb]};
@@ -1329,12 +1363,17 @@ __device__ __forceinline__ void leafscan_chunks(const LeafScanParams &p, const u
         if (DPF_ABLATION(p, 1)) {                            // ablation runs: loads and products only
             float t = 0.f;
 #pragma unroll
-            for (int rb = 0; rb < RB; rb++) t += acc[rb][rb];
+            for (int rb = 0; rb < RB; rb++) t += (float)acc[rb][rb];
             if (t == 12345.678f) nbuf = 1;
             continue;
         }
         // the common case first: nothing of this lane's 16 scores reaches its query's threshold
-        {
+        if constexpr (I8) {
+            const float4 Gs = *(const float4 *)(s_G + 4 * g);
+            const int any = (int)(best_of<RB>(acc, 0) >= __float_as_int(Gs.x)) | (int)(best_of<RB>(acc, 1) >= __float_as_int(Gs.y)) |
+                            (int)(best_of<RB>(acc, 2) >= __float_as_int(Gs.z)) | (int)(best_of<RB>(acc, 3) >= __float_as_int(Gs.w));
+            if (__ballot(any != 0) == 0) continue;
+        } else {
             const float4 Gs = *(const float4 *)(s_G + 4 * g);
             const float e0 = best_of<RB>(acc, 0) - Gs.x;
             const float e1 = best_of<RB>(acc, 1) - Gs.y;
@@ -1345,7 +1384,8 @@ __device__ __forceinline__ void leafscan_chunks(const LeafScanParams &p, const u
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int slot = 4 * g + r;
-            const float Gr = s_G[slot];
+            val Gr;
+            if constexpr (I8) Gr = __float_as_int(s_G[slot]); else Gr = s_G[slot];
             if (__ballot(best_of<RB>(acc, r) >= Gr) == 0) continue;
             const float4 sc = s_slot[slot];           // {G2, query index, |q - q~| or slack, |q~|^2}
             const int32_t qq = __float_as_int(sc.y), qidq = s_qid[slot];
@@ -1371,9 +1411,9 @@ __device__ __forceinline__ void leafscan_chunks(const LeafScanParams &p, const u
                 if (__ballot(first) == 0) continue;
                 float t2lo, t2hi;
                 tail2(rb, t2lo, t2hi);
-                const float d2 = fmaf(-0.5f, t2lo, acc[rb][r]);
+                const float d2 = fmaf(-0.5f, t2lo, (float)acc[rb][r]);     // (int8: the integer itself, exact in fp32)
                 if (METRIC == 1) tight += first && d2 >= sc.x ? 1 : 0;
-                const bool fwd = first && d2 >= Gr && !self_excluded(idj[rb], qidq, p.exclude_self);
+                const bool fwd = first && (I8 || d2 >= Gr) && !self_excluded(idj[rb], qidq, p.exclude_self);
                 const unsigned long long m = __ballot(fwd);
                 if (m) {
                     if (fwd) {
@@ -1384,7 +1424,11 @@ __device__ __forceinline__ void leafscan_chunks(const LeafScanParams &p, const u
                         // so 2 c32 |x~|^2 <= 4.001 c32 J),
                         // sqrt(exact distance) <= sqrt(s_hi) + |x - x~|max + |q - q~|, the query's share is added by
                         // the reader; dot: exact product >= q~.x~ - slack
-                        if (METRIC == 1) {
+                        if constexpr (I8) {
+                            // d >= d_int - 1/2, so |q' - x'|^2 = |q'|^2 - 2 d <= |q'|^2 - 2 d_int + 1
+                            const float s_hi = fmaf(-2.0f, (float)acc[rb][r], sc.w) + 1.0f;
+                            s_fv[at] = sqrtf(fmaxf(s_hi, 0.f) * 1.000001f) * 1.000001f + cxm;
+                        } else if (METRIC == 1) {
                             const float s_hi = fmaf(-2.0f, acc[rb][r], sc.w * (1.0f + c32) - 4.001f * c32 * nJ[rb]) + t2hi;
                             s_fv[at] = sqrtf(fmaxf(s_hi, 0.f) * 1.000001f) * 1.000001f + cxm;
                         } else {
@@ -1419,7 +1463,9 @@ __device__ __forceinline__ void leafscan_chunks(const LeafScanParams &p, const u
                     const bool ok = idj[rb] >= 0 && !self_excluded(idj[rb], qidq, p.exclude_self);
                     float t2lo, t2hi;
                     tail2(rb, t2lo, t2hi);
-                    const float s_hi = fmaf(-2.0f, acc[rb][r], sc.w * (1.0f + c32) - 4.001f * c32 * nJ[rb]) + t2hi;
+                    float s_hi;
+                    if constexpr (I8) s_hi = fmaf(-2.0f, (float)acc[rb][r], sc.w) + 1.0f;
+                    else s_hi = fmaf(-2.0f, acc[rb][r], sc.w * (1.0f + c32) - 4.001f * c32 * nJ[rb]) + t2hi;
                     v[rb] = ok ? sqrtf(fmaxf(s_hi, 0.f) * 1.000001f) * 1.000001f + cxm : HUGE_VALF;
                 }
                 // rank of each of this lane's RB values among the group's 16*RB, one value at a time: the path
@@ -1466,12 +1512,16 @@ __device__ __forceinline__ void leafscan_flush_rest(const LeafScanParams &p, con
 // first queries) and once per further chunk; the other waves of the SIMD fill those waits.
 // RB*16 rows per tile: 64 measured best on gfx950 (32-row tiles double the per-unit work and
 // were 1.9x slower in spite of the higher occupancy).
-constexpr int ls16_waves(int ks, int rb) { return ks > 8 && rb == 4 ? 1 : ks >= 8 ? 2 : LS16_WAVES4; }
+#ifndef LS8_WAVES
+#define LS8_WAVES 4
+#endif
+constexpr int ls16_waves(int ks, int rb, bool i8 = false) { return i8 && ks <= 2 ? LS8_WAVES : ks > 8 && rb == 4 ? 1 : ks >= 8 ? 2 : LS16_WAVES4; }
 
-template <int KS, int METRIC, int RB, bool TAIL>
-__global__ __launch_bounds__(256, ls16_waves(KS, RB)) void k_leafscan_f16(LeafScanParams p, const uint16_t *__restrict__ Q16,
+template <int KS, int METRIC, int RB, bool TAIL, bool I8 = false>
+__global__ __launch_bounds__(256, ls16_waves(KS, RB, I8)) void k_leafscan_f16(LeafScanParams p, const uint16_t *__restrict__ Q16,
                                                                           const uint16_t *__restrict__ B16)
 {
+    if (p.gate && (*p.gate != 0) != (p.gate_want != 0)) return;     // the other form of the scan answers this batch
     __shared__ uint4 s_qt[4][TAIL ? 16 : 1];              // the chunk's query tails and their squared norms
     __shared__ float s_qt2[4][TAIL ? 16 : 1];
     __shared__ uint4 s_xt[4][TAIL ? 64 : 1];              // the tile's row tails
@@ -1535,7 +1585,7 @@ __global__ __launch_bounds__(256, ls16_waves(KS, RB)) void k_leafscan_f16(LeafSc
     for (; u < nunits;) {
         // this unit's rows
         f16x8 xb[RB][KS];
-        float nJ[RB];                                     // minus the row's share of the threshold, -|x~|^2 (1 - c32) / 2;
+        typename ScanTypes<I8>::val nJ[RB];               // minus the row's share of the threshold, -|x~|^2 (1 - c32) / 2;
                                                           // -inf for an absent row, which then never reaches any threshold
         const uint32_t rows = U0.y & 0xffu;               // 16-row blocks past the tile's end are skipped throughout
         const uint32_t tile_slot0 = U0.x;
@@ -1557,14 +1607,16 @@ __global__ __launch_bounds__(256, ls16_waves(KS, RB)) void k_leafscan_f16(LeafSc
             const uint16_t *row = B16 + at * STRIDE + 8 * g;
 #pragma unroll
             for (int t = 0; t < KS; t++) xb[rb][t] = *(const f16x8 *)(row + 32 * t);
-            nJ[rb] = rb * 16u + (uint32_t)i16 < rows ? p.slot_norm[tile_slot0 + rb * 16u + (uint32_t)i16] : 0.f;
+            if constexpr (I8) nJ[rb] = rb * 16u + (uint32_t)i16 < rows ? p.slot_nj8[tile_slot0 + rb * 16u + (uint32_t)i16] : 0;
+            else nJ[rb] = rb * 16u + (uint32_t)i16 < rows ? p.slot_norm[tile_slot0 + rb * 16u + (uint32_t)i16] : 0.f;
         }
         int32_t idj[RB];
 #pragma unroll
         for (int rb = 0; rb < RB; rb++) {
             idj[rb] = id0[rb];
             const bool there = id0[rb] >= 0 && (rb == 0 || rb * 16u < rows);
-            nJ[rb] = there ? (METRIC == 1 ? -0.5f * nJ[rb] * (1.0f - leafscan_c32(STRIDE)) : 0.f) : -HUGE_VALF;
+            if constexpr (I8) nJ[rb] = there ? nJ[rb] : I8_ABSENT;
+            else nJ[rb] = there ? (METRIC == 1 ? -0.5f * nJ[rb] * (1.0f - leafscan_c32(STRIDE)) : 0.f) : -HUGE_VALF;
         }
         const uint32_t nq = U0.y >> 8, lq0 = U0.z;
         const float xrm = __uint_as_float(U0.w & 0xffff0000u);    // upper bound of the largest |x~| of the tile
@@ -1579,7 +1631,7 @@ __global__ __launch_bounds__(256, ls16_waves(KS, RB)) void k_leafscan_f16(LeafSc
         u_after = unit_of(3u * places + (uint32_t)__builtin_amdgcn_readfirstlane((int)pend));
         if (lane == 0) pend = atomicAdd(ctr, 1u);
         small(U0, id0, qs0);
-        leafscan_chunks<KS, METRIC, RB, TAIL>(p, Q16, xb, nJ, idj, rows, nq, lq0, xrm, cxm, qsc, qsn, s_fq[wave], s_fid[wave], s_fv[wave],
+        leafscan_chunks<KS, METRIC, RB, TAIL, I8>(p, Q16, xb, nJ, idj, rows, nq, lq0, xrm, cxm, qsc, qsn, s_fq[wave], s_fid[wave], s_fv[wave],
                                               s_slot[wave], s_G[wave], s_qid[wave], nbuf, s_xt[wave], s_qt[wave], s_qt2[wave]);
     }
     leafscan_flush_rest(p, s_fq[wave], s_fid[wave], s_fv[wave], nbuf);
@@ -1588,7 +1640,7 @@ __global__ __launch_bounds__(256, ls16_waves(KS, RB)) void k_leafscan_f16(LeafSc
 template <int METRIC, int RB>
 static void launch_leafscan_f16_m(const LeafScanParams &p, hipStream_t stream)
 {
-    const int64_t resident = (int64_t)p.num_cus * ls16_waves(p.ks, RB);   // workgroups the chip holds at once
+    const int64_t resident = (int64_t)p.num_cus * ls16_waves(p.ks, RB, p.i8 != 0);   // workgroups the chip holds at once
     const int64_t n = p.totals ? resident * 4 : p.unit_end - p.unit_begin;
     if (n <= 0) return;
     dim3 grid((unsigned)std::min<int64_t>((n + 3) / 4, resident)), block(256);
@@ -1601,6 +1653,19 @@ static void launch_leafscan_f16_m(const LeafScanParams &p, hipStream_t stream)
         }                                                                                                                \
         hipLaunchKernelGGL((k_leafscan_f16<KS, METRIC, RB, false>), grid, block, 0, stream, q, q.Q16, q.base16);         \
     } while (0)
+    if constexpr (RB == 4 && METRIC == 1) {
+        if (p.i8) {
+#define DPF_LB8(KS) hipLaunchKernelGGL((k_leafscan_f16<KS, 1, 4, false, true>), grid, block, 0, stream, q, q.Q16, q.base16)
+            switch (p.ks) {
+            case 1: DPF_LB8(1); break;
+            case 2: DPF_LB8(2); break;
+            case 3: DPF_LB8(3); break;
+            default: DPF_LB8(4); break;
+            }
+#undef DPF_LB8
+            return;
+        }
+    }
     if constexpr (RB == 4) {
         switch (p.ks) {
         case 1: DPF_LB(1); break;
@@ -1853,6 +1918,98 @@ void launch_rows_to_f16(const float *src, int64_t src_stride, int dim, int64_t n
     else hipLaunchKernelGGL((k_rows_to_f16<false>), grid, block, 0, stream, src, src_stride, dim, n, dst, dst_stride, norms, errs, tp, dim_all, tails);
 }
 
+// ---------------------------------------------------------------------------
+// int8 copies for the exact integer form of the scan
+// ---------------------------------------------------------------------------
+// smallest and largest value of the rows and whether any value is no integer (NaN counts as one)
+__global__ __launch_bounds__(256) void k_i8_range(const float *__restrict__ src, int64_t src_stride, int dim, int64_t n,
+                                                  int32_t *__restrict__ out)
+{
+    float lo = HUGE_VALF, hi = -HUGE_VALF;
+    int nonint = 0;
+    const int64_t total = n * dim;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / dim;
+        const float x = src[r * src_stride + (i - r * dim)];
+        lo = fminf(lo, x); hi = fmaxf(hi, x);
+        nonint |= !(x == rintf(x)) ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = fminf(lo, __shfl_xor(lo, o)); hi = fmaxf(hi, __shfl_xor(hi, o));
+        nonint |= __shfl_xor(nonint, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(out, enc_f32(lo));
+        atomicMax(out + 1, enc_f32(hi));
+        if (nonint) atomicOr(out + 2, 1);
+    }
+}
+void launch_i8_range(const float *src, int64_t src_stride, int dim, int64_t n, int32_t *out, hipStream_t stream)
+{
+    if (n <= 0) return;
+    const int64_t total = n * dim;
+    const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(k_i8_range, dim3(blocks), dim3(256), 0, stream, src, src_stride, dim, n, out);
+}
+
+// 16 lanes per row, a lane converts 16 consecutive elements (rows of up to 256 bytes)
+template <bool QUERY>
+__global__ __launch_bounds__(256) void k_rows_to_i8(const float *__restrict__ src, int64_t src_stride, int dim, int64_t n, float offset,
+                                                    int8_t *__restrict__ dst, int dst_stride, int32_t *__restrict__ norm2,
+                                                    float4 *__restrict__ qc, const int32_t *__restrict__ qids, int32_t *__restrict__ bad)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t r = i >> 4;
+    const int c0 = (int)(i & 15) * 16;
+    const bool live = r < n && c0 < dst_stride;
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+    int32_t sum = 0, wrong = 0;
+    if (live) {
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            int32_t v = 0;
+            if (c0 + e < dim) {
+                const float f = src[r * src_stride + c0 + e] - offset;
+                if (!(f == rintf(f)) || f < -128.0f || f > 127.0f) wrong = 1;
+                else v = (int32_t)f;
+            }
+            sum += v * v;
+            w[e >> 2] |= (uint32_t)(v & 0xff) << (8 * (e & 3));
+        }
+        *(uint4 *)(dst + r * dst_stride + c0) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) { sum += __shfl_xor(sum, o); wrong |= __shfl_xor(wrong, o); }
+    if (r < n && c0 == 0) {
+        if (wrong) atomicOr(bad, 1);
+        if (QUERY) qc[r] = make_float4(0.5f * (float)sum, 0.f, (float)sum, __int_as_float(qids ? qids[r] : -1));
+        else norm2[r] = sum;
+    }
+}
+void launch_rows_to_i8(const float *src, int64_t src_stride, int dim, int64_t n, float offset, int8_t *dst, int dst_stride,
+                       int32_t *norm2, float4 *qc, const int32_t *qids, int32_t *bad, hipStream_t stream)
+{
+    if (n <= 0) return;
+    const dim3 grid((unsigned)((n * 16 + 255) / 256)), block(256);
+    if (qc) hipLaunchKernelGGL((k_rows_to_i8<true>), grid, block, 0, stream, src, src_stride, dim, n, offset, dst, dst_stride, norm2, qc, qids, bad);
+    else hipLaunchKernelGGL((k_rows_to_i8<false>), grid, block, 0, stream, src, src_stride, dim, n, offset, dst, dst_stride, norm2, qc, qids, bad);
+}
+
+__global__ __launch_bounds__(256) void k_slot_nj8(const int32_t *__restrict__ ids, int64_t nslots, const int32_t *__restrict__ norm2,
+                                                  int64_t row_begin, int64_t row_end, int32_t *__restrict__ slot_nj8)
+{
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= nslots) return;
+    const int64_t id = ids[s];
+    slot_nj8[s] = id >= row_begin && id < row_end ? -(norm2[id - row_begin] >> 1) : I8_ABSENT;
+}
+void launch_slot_nj8(const int32_t *ids, int64_t nslots, const int32_t *norm2, int64_t row_begin, int64_t row_end,
+                     int32_t *slot_nj8, hipStream_t stream)
+{
+    if (nslots > 0) hipLaunchKernelGGL(k_slot_nj8, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, stream, ids, nslots, norm2, row_begin, row_end, slot_nj8);
+}
+
 void launch_leafscan(int metric, const LeafScanParams &p, hipStream_t stream)
 {
     if (leafscan_tile_rows(p.ks) == 16) {
@@ -1868,8 +2025,8 @@ void launch_leafscan(int metric, const LeafScanParams &p, hipStream_t stream)
 int leafscan_tile_rows(int ks) { return ks > 24 ? 16 : 64; }
 
 // flag[0] = number of queries whose forward list overflowed, their indices in list[]; flag[2] = the longest forward
-// list of the batch.  One workgroup (the batch's counts are a few tens of KB); its last act is to copy the 32-byte
-// record at flag[] (four flag words, two scan totals) into pinned host memory, where the host reads it after its wait
+// list of the batch.  One workgroup (the batch's counts are a few tens of KB); its last act is to copy the 40-byte
+// record at flag[] (four flag words, two scan totals, the int8 gate word) into pinned host memory, where the host reads it after its wait
 // on the stream: no separate device-to-host copy.
 __global__ __launch_bounds__(1024) void k_overflow_list(const int32_t *__restrict__ emit_cnt, int64_t nq, int32_t cap, int32_t *flag,
                                                         int32_t *__restrict__ list, int32_t *__restrict__ host_record)
@@ -1885,7 +2042,7 @@ __global__ __launch_bounds__(1024) void k_overflow_list(const int32_t *__restric
     if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(flag + 2, m);
     __threadfence();
     __syncthreads();
-    if (threadIdx.x < 8) {
+    if (threadIdx.x < 10) {
         host_record[threadIdx.x] = __hip_atomic_load(flag + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __threadfence_system();
     }

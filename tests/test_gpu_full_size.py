@@ -106,7 +106,9 @@ def test_c4_sift_shaped_1m_base_10k_queries():
     # 128-d integer-valued 0..255 rows (SIFT-shaped), forest as c3
     params, X, Q, pick, steps, orc, gpu = _fit_both("c4", 1_000_000, 10_000)
     assert X.shape[1] == 128 and float(X.max()) == 255.0
-    _check_batch(params, X, Q, pick, steps, orc, gpu, sample=128, set_steps=(0, 1))
+    st = _check_batch(params, X, Q, pick, steps, orc, gpu, sample=128, set_steps=(0, 1))
+    # integer-valued rows and queries inside one window of 256 values: scanned in int8 (exact integer products)
+    assert st["last_scan_int8"] == 1 and gpu.stats()["base8_bytes"] == 1_000_000 * 128
 
 
 def test_c5_share_768d_unit_gaussian():

@@ -1019,3 +1019,114 @@ def test_scan_in_two_or_three_passes(dim, passes, early, first):
     assert fast.stats()["last_scan_launches"] <= want
     with pytest.raises(Exception):
         fast.set_option("scan_passes", 4)
+
+
+def _integer_problem(n, nq, dim, lo, seed, spread=12.0, n_clusters=12, **kw):
+    """Integer-valued rows and queries inside the window [lo, lo + 255] (SIFT-shaped when lo = 0)."""
+    params, _, _, _ = make_problem(n=16, nq=2, dim=dim, **kw)
+    rng = np.random.default_rng(seed)
+    centres = rng.integers(lo + 20, lo + 236, size=(n_clusters, dim)).astype(np.float32)
+    lab = rng.integers(0, n_clusters, size=n)
+    X = np.clip(np.rint(centres[lab] + spread * rng.standard_normal((n, dim), dtype=np.float32)), lo, lo + 255).astype(np.float32)
+    pick = rng.integers(0, n, size=nq)
+    Q = np.clip(np.rint(X[pick] + 4.0 * rng.standard_normal((nq, dim), dtype=np.float32)), lo, lo + 255).astype(np.float32)
+    return params, np.ascontiguousarray(X), np.ascontiguousarray(Q), pick.astype(np.int32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim,lo", [(128, 0), (100, 0), (24, -128), (64, 1000), (65, 0), (200, -300), (256, 0), (192, 7)])
+def test_int8_scan_equals_fp16_scan_and_gather(dim, lo):
+    # l2 handles whose rows are all integers inside one window of 256 values keep an int8 copy; a batch of integer
+    # queries inside the window is scanned with exact integer products (v_mfma_i32_16x16x64_i8): the answers are those of
+    # the fp16 scan (DPF_FLAG_NO_INT8) and of the gather path, bit for bit; a batch with a query that does not fit the
+    # window takes the fp16 scan
+    n, nq = 9000, 160
+    params, X, Q, pick = _integer_problem(n, nq, dim, lo, seed=dim + 7, bucket_overflow=50, table_num=2, permutation_num=2)
+    X[5] = X[4]; X[6] = X[4]                                       # equal rows: ties by id
+    X[0, 0] = lo; X[1, 0] = lo + 255                                # the window's ends are there
+    i8 = DpfIndex(params, metric="l2")
+    f16 = DpfIndex(dict(params, flags=16), metric="l2")            # DPF_FLAG_NO_INT8
+    slow = DpfIndex(dict(params, flags=2), metric="l2")            # DPF_FLAG_GATHER_ONLY
+    for ix in (i8, f16, slow):
+        ix.fit(X)
+    assert i8.stats()["base8_bytes"] == n * ((dim + 63) // 64) * 64
+    assert f16.stats()["base8_bytes"] == 0 and slow.stats()["base8_bytes"] == 0
+    for steps, k in ((1, 10), (3, 1), (0, 64), (1, 10)):
+        ii, is_ = i8.query_topk(pick, Q, steps=steps, k=k)
+        st = i8.stats()
+        # (windows far from zero make the sign hashes nearly constant: a handful of huge buckets, and a 3-step batch
+        # may overflow its forward lists and end on the gather path - still the same answer)
+        assert (st["last_path"] == 1 and st["last_scan_int8"] == 1) or (abs(lo) > 255 and steps != 1)
+        fi, fs = f16.query_topk(pick, Q, steps=steps, k=k)
+        assert f16.stats()["last_scan_int8"] == 0
+        si, ss = slow.query_topk(pick, Q, steps=steps, k=k)
+        assert np.array_equal(ii, si) and np.array_equal(is_, ss, equal_nan=True)
+        assert np.array_equal(fi, si) and np.array_equal(fs, ss, equal_nan=True)
+    # the exact filter forwards no more than the fp16 one (whose thresholds carry rounding allowances), up to the half
+    # unit the integer test gives away
+    assert i8.stats()["last_forwarded"] <= 1.05 * f16.stats()["last_forwarded"] + nq
+    # queries without ids (nothing excluded), and the no-threshold start (fewer candidates than k)
+    ii, is_ = i8.query_topk(None, Q, steps=2, k=10)
+    si, ss = slow.query_topk(None, Q, steps=2, k=10)
+    assert i8.stats()["last_scan_int8"] == 1 and np.array_equal(ii, si) and np.array_equal(is_, ss, equal_nan=True)
+    # one query off the integers or outside the window: those batches are scanned in fp16, same answers
+    for bad in (lo + 0.5, lo + 256.0, lo - 1.0):
+        Q2 = Q.copy()
+        Q2[nq // 2, dim - 1] = bad
+        ii, is_ = i8.query_topk(pick, Q2, steps=1, k=10)
+        st = i8.stats()
+        assert st["last_path"] == 1 and st["last_scan_int8"] == 0
+        si, ss = slow.query_topk(pick, Q2, steps=1, k=10)
+        assert np.array_equal(ii, si) and np.array_equal(is_, ss, equal_nan=True)
+    ii, is_ = i8.query_topk(pick, Q, steps=1, k=10)               # and back
+    assert i8.stats()["last_scan_int8"] == 1
+    si, ss = slow.query_topk(pick, Q, steps=1, k=10)
+    assert np.array_equal(ii, si) and np.array_equal(is_, ss, equal_nan=True)
+    for ix in (i8, f16, slow):
+        ix.close()
+
+
+@pytest.mark.gpu
+def test_int8_copy_only_where_the_rows_allow_it():
+    n, nq, dim = 3000, 40, 96
+    params, X, Q, pick = _integer_problem(n, nq, dim, 0, seed=3, bucket_overflow=50, table_num=2, permutation_num=1)
+    slow = DpfIndex(dict(params, flags=2), metric="l2")
+    slow.fit(X)
+    si, ss = slow.query_topk(pick, Q, steps=1, k=10)
+
+    def check(Xv, want_i8, metric="l2"):
+        ix = DpfIndex(params, metric=metric)
+        ix.fit(Xv)
+        assert (ix.stats()["base8_bytes"] > 0) == want_i8
+        got = ix.query_topk(pick, Q, steps=1, k=10)
+        assert ix.stats()["last_scan_int8"] == (1 if want_i8 else 0)
+        ix.close()
+        return got
+
+    ii, is_ = check(X, True)
+    assert np.array_equal(ii, si) and np.array_equal(is_, ss, equal_nan=True)
+    check(X, False, metric="dot")                                  # the int8 form is an l2 filter
+    Xh = X.copy(); Xh[17, 3] += 0.25                               # one value off the integers
+    check(Xh, False)
+    Xw = X.copy(); Xw[17, 3] = 256.0                               # 257 values wide
+    check(Xw, False)
+    # a second fit that breaks the window drops the copy, one that keeps it keeps it
+    ix = DpfIndex(params, metric="l2")
+    ix.fit(X[:2000])
+    assert ix.stats()["base8_bytes"] == 2000 * 128
+    ix.fit(X[2000:])
+    assert ix.stats()["base8_bytes"] == n * 128
+    ii, is_ = ix.query_topk(pick, Q, steps=1, k=10)
+    assert ix.stats()["last_scan_int8"] == 1 and np.array_equal(ii, si) and np.array_equal(is_, ss, equal_nan=True)
+    ix.fit(Xh[:50])
+    assert ix.stats()["base8_bytes"] == 0
+    ix.query_topk(pick, Q, steps=1, k=10)
+    assert ix.stats()["last_scan_int8"] == 0
+    ix.close()
+    # more than 256 dimensions: no int8 rows
+    p2, X2, Q2, pick2 = _integer_problem(2000, 20, 300, 0, seed=4, bucket_overflow=50, table_num=2, permutation_num=1)
+    ix = DpfIndex(p2, metric="l2")
+    ix.fit(X2)
+    assert ix.stats()["base8_bytes"] == 0
+    ix.close()
+    slow.close()
