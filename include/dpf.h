@@ -60,7 +60,7 @@ enum { DPF_FLAG_HASH_ONLY = 1,
  * pass: the same filter in two stages, same results, fewer bytes per scanned row (the flag is for A/B). */
        DPF_FLAG_FULL_FILTER = 8,
 /* DPF_FLAG_NO_INT8: never scan in int8.  Without it an l2 handle of up to 256 dimensions whose resident rows are all
- * integer-valued inside one window of 256 values (SIFT's 0..255) keeps an int8 copy of them beside the fp16 one, and a
+ * integer-valued inside one window of 256 values within +-2048 (SIFT's 0..255) keeps an int8 copy of them beside the fp16 one, and a
  * batch whose queries fit the window too is scanned with exact integer products on half the bytes (same results;
  * other batches take the fp16 scan; the flag is for A/B). */
        DPF_FLAG_NO_INT8 = 16 };
@@ -301,7 +301,9 @@ enum {
                                         Default 4096; 0 = never; 1 = always, whatever the shape */
     DPF_OPT_SCAN_PASSES = 8,         /* slices the scan's work units are run in, thresholds refined in between: 2, 3, or
                                         0 = 3 for rows of 16 steps of 32 dimensions and more, 2 otherwise */
-    DPF_OPT_EARLY_PASS_PERMILLE = 9  /* with 3 passes: share of the units in the first of them (40) */
+    DPF_OPT_EARLY_PASS_PERMILLE = 9, /* with 3 passes: share of the units in the first of them (40) */
+    DPF_OPT_EXACT_SEEDS = 10         /* 1: l2 handles score the seed sample exactly from the fp32 rows, as dot handles do
+                                        (default 0: an upper bound of the k-th best distance from the fp16 copies) */
 };
 int dpf_set_option(dpf_index *ix, int32_t option, int64_t value);
 

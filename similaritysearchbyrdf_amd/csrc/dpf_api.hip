@@ -191,7 +191,7 @@ struct dpf_index {
     // dpf_set_option values (0 / default = the library's own choice)
     int32_t opt_emit_cap = 0, opt_bucket_list_cap = 0, opt_first_permille = 100, opt_seed_cap = 256;
     int32_t opt_scan_passes = 0, opt_early_permille = 40;   // passes: 0 = by row length (3 from 16 steps on), 2 or 3
-    bool opt_sync_sizes = false, opt_short_rerank = true;
+    bool opt_sync_sizes = false, opt_short_rerank = true, opt_exact_seeds = false;
     int64_t opt_projection_min_rows = 4096;           // batches of at least this many vectors hash on the matrix cores (0: never)
 };
 
@@ -632,7 +632,9 @@ static int finish_fit(dpf_index *ix, int64_t total, int64_t new_rows)
         HIPCHECK(ix, hipMemcpy(got, ix->d_i8_probe.p, 16, hipMemcpyDeviceToHost));
         auto dec = [](int32_t b2) { b2 = b2 >= 0 ? b2 : (b2 ^ 0x7fffffff); float f; memcpy(&f, &b2, 4); return f; };
         const float lo = dec(got[0]), hi = dec(got[1]);
-        if (got[2] == 0 && std::isfinite(lo) && std::isfinite(hi) && hi - lo <= 255.0f && std::fabs(lo) <= 1.0e6f && std::fabs(hi) <= 1.0e6f) {
+        // (within +-2048 every integer is an fp16 value too: the thresholds the two forms of the scan share - seed radii,
+        // refinements - then carry no rounding allowance for such a batch)
+        if (got[2] == 0 && std::isfinite(lo) && std::isfinite(hi) && hi - lo <= 255.0f && std::fabs(lo) <= 2048.0f && std::fabs(hi) <= 2048.0f) {
             ix->ks8 = (d + 63) / 64;
             ix->i8_offset = lo + 128.0f;
             HIPCHECK(ix, ix->d_base8.ensure((size_t)new_rows * ix->ks8 * 64));
@@ -1215,7 +1217,10 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
         launch_unique_lists(ix->ws_seed_cand.as<int32_t>(), ix->ws_seed_cnt.as<int32_t>(), SEED_CAP, SEED_CAP, ix->ws_emit_ucnt.as<int32_t>(), nq, stream);
         rp.cnt = ix->ws_emit_ucnt.as<int32_t>();
     }
-    if (SEED_CAP > 0) {
+    // l2: the first radii come from the fp16 copies (k_seed_radius, behind the query conversion below: an upper bound is
+    // all the scan needs, at half the bytes per seed row); dot, or on request: exact scores of the fp32 rows
+    const bool seeds_fp16 = SEED_CAP > 0 && ix->cfg.metric == DPF_METRIC_L2 && !ix->opt_exact_seeds;
+    if (SEED_CAP > 0 && !seeds_fp16) {
         if (short_lists && rerank_short_applies(rp)) launch_rerank_short(ix->cfg.dtype, ix->cfg.metric, rp, nq, stream);
         else launch_rerank(ix->cfg.dtype, ix->cfg.metric, rp, nq, stream);
     }
@@ -1228,12 +1233,18 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     {   // the conversion's last lane of every query row also writes the query's first threshold and scan record
         TauParams tp;
         tp.metric = ix->cfg.metric;
-        if (SEED_CAP > 0) { tp.seed_scores = ix->ws_seed_scores.as<double>(); tp.seed_ids = ix->ws_seed_ids.as<int32_t>(); }
+        if (SEED_CAP > 0 && !seeds_fp16) { tp.seed_scores = ix->ws_seed_scores.as<double>(); tp.seed_ids = ix->ws_seed_ids.as<int32_t>(); }
         tp.k = k; tp.qids = d_qids; tp.tau = ix->ws_tau.as<int32_t>(); tp.qc = (float4 *)ix->ws_qc.p;
         const bool tails = ix->filter_dim < ix->cfg.dim;
         if (tails) HIPCHECK(ix, ix->ws_q16t.ensure((size_t)nq * 16));
         launch_rows_to_f16((const float *)qpad, ix->dpad, std::min(ix->cfg.dim, ix->filter_dim), nq, ix->ws_q16.as<uint16_t>(), ix->ks16 * 32,
-                           ix->ws_q16n.as<float>(), ix->ws_q16e.as<float>(), stream, &tp, ix->cfg.dim, tails ? (uint4 *)ix->ws_q16t.p : nullptr);
+                           ix->ws_q16n.as<float>(), ix->ws_q16e.as<float>(), stream, seeds_fp16 ? nullptr : &tp, ix->cfg.dim,
+                           tails ? (uint4 *)ix->ws_q16t.p : nullptr);
+        if (seeds_fp16)
+            launch_seed_radius(rp.cand, rp.cnt, SEED_CAP, ix->ws_q16.as<uint16_t>(), ix->d_base16.as<uint16_t>(), ix->ks16,
+                               ix->ws_q16n.as<float>(), ix->ws_q16e.as<float>(), ix->d_base16e.as<float>(),
+                               tails ? (const uint4 *)ix->ws_q16t.p : nullptr, tails ? (const uint4 *)ix->d_base16t.p : nullptr,
+                               ix->row_begin, ix->row_begin + ix->base_rows, tp, nq, stream);
     }
     // int8 rows of the queries where the index has an int8 copy; flags[8] is raised when a query does not fit its window
     int32_t *const i8_gate = flags + 8;
@@ -1656,6 +1667,9 @@ extern "C" int dpf_set_option(dpf_index *ix, int32_t option, int64_t value)
         return DPF_OK;
     case DPF_OPT_SHORT_RERANK:
         ix->opt_short_rerank = value != 0;
+        return DPF_OK;
+    case DPF_OPT_EXACT_SEEDS:
+        ix->opt_exact_seeds = value != 0;
         return DPF_OK;
     case DPF_OPT_PROJECTION_MIN_ROWS:
         if (value < 0) return fail(ix, DPF_EINVAL, "dpf_set_option: the row count must not be negative");

@@ -191,6 +191,10 @@ void launch_rows_to_i8(const float *src, int64_t src_stride, int dim, int64_t n,
                        int32_t *norm2, float4 *qc, const int32_t *qids, int32_t *bad, hipStream_t stream);
 void launch_slot_nj8(const int32_t *ids, int64_t nslots, const int32_t *norm2, int64_t row_begin, int64_t row_end,
                      int32_t *slot_nj8, hipStream_t stream);
+// first thresholds (l2) and scan records of a batch from the fp16 copies of the queries and of their seed rows
+void launch_seed_radius(const int32_t *cand, const int32_t *cnt, int64_t cand_stride, const uint16_t *Q16, const uint16_t *B16, int ks,
+                        const float *q_norm, const float *q_err, const float *b_err, const uint4 *q_tail, const uint4 *b_tail,
+                        int64_t row_begin, int64_t row_end, const TauParams &tau, int64_t nq, hipStream_t stream);
 size_t unique_lists_lds(int32_t longest);
 void launch_unique_lists(int32_t *emit, const int32_t *emit_cnt, int32_t cap, int32_t longest, int32_t *unique_cnt, int64_t nq,
                          hipStream_t stream);

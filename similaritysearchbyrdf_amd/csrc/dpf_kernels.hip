@@ -1229,6 +1229,28 @@ __device__ __forceinline__ float tail_dot(const uint4 &a, const uint4 &b)
     return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, a.w), __builtin_bit_cast(f16x2, b.w), c, false);
 }
 
+// Coalesced operand loads (COAL).  The matrix cores want lane (g, i16) to hold bytes 16 g .. 16 g + 15 of row i16's
+// 64-byte step, so a plain operand load has neighbouring lanes on 16 different rows: 64 cache look-ups per instruction.
+// Loaded the other way round - lane quad j reads the 64 consecutive bytes of row pi(j) = 4 (j % 4) + j / 4, one look-up
+// per quad - the same registers are a lane permutation away from operand shape: lane (g, m, y) takes what lane (y, m, g)
+// loaded (the two 2-bit ends of the lane number change places), four ds_bpermute per 16-byte register, no LDS memory.
+#ifndef LS8_COAL
+#define LS8_COAL 1
+#endif
+#ifndef LS16_COAL
+#define LS16_COAL 0
+#endif
+__device__ __forceinline__ f16x8 operand_from_quads(const f16x8 &v, int src4)
+{
+    const i32x4 w = __builtin_bit_cast(i32x4, v);
+    i32x4 o;
+    o[0] = __builtin_amdgcn_ds_bpermute(src4, w[0]);
+    o[1] = __builtin_amdgcn_ds_bpermute(src4, w[1]);
+    o[2] = __builtin_amdgcn_ds_bpermute(src4, w[2]);
+    o[3] = __builtin_amdgcn_ds_bpermute(src4, w[3]);
+    return __builtin_bit_cast(f16x8, o);
+}
+
 // The queries of one unit against the tile a wave holds in registers, 16 at a time: thresholds,
 // products on the matrix cores, tests, forwarding.  s_* are this wave's LDS areas: forwarded (query,
 // id, bound) triples parked until 64 are there; per query slot the threshold G, and for the rare
@@ -1253,7 +1275,7 @@ __device__ __forceinline__ float tail_dot(const uint4 &a, const uint4 &b)
 // at most a few fp32 ulps of |q_t|^2 + |x_t|^2, is covered by the slack 2e-6 (|q_t|^2 + |x_t|^2)) is put back:
 // d - t2_lo / 2 is the d of the whole fp16 rows (rounded towards keeping the row), s_hi + t2_hi their squared
 // distance from above.  Norms in the thresholds are the cut vectors', rounding distances the whole rows'.
-template <int KS, int METRIC, int RB, bool TAIL, bool I8>
+template <int KS, int METRIC, int RB, bool TAIL, bool I8, bool COAL>
 __device__ __forceinline__ void leafscan_chunks(const LeafScanParams &p, const uint16_t *__restrict__ Q16, const f16x8 (&xb)[RB][KS],
                                                 const typename ScanTypes<I8>::val (&nJ)[RB], const int32_t (&idj)[RB], uint32_t rows, uint32_t nq,
                                                 uint32_t lq0, float xrm, float cxm, int32_t qsc, int32_t qsn, int32_t *s_fq,
@@ -1263,6 +1285,7 @@ __device__ __forceinline__ void leafscan_chunks(const LeafScanParams &p, const u
     static_assert(!TAIL || METRIC == 1, "tails belong to the l2 filter");
     static_assert(RB == 4 || RB == 1, "64-row tiles, or 16-row tiles for rows of more than 768 dimensions");
     static_assert(!I8 || (METRIC == 1 && RB == 4 && !TAIL && KS <= 4), "the int8 scan: l2, 64-row tiles, rows of up to 256 bytes");
+    static_assert(!COAL || KS <= 8, "coalesced operand loads: whole query rows in registers");
     typedef typename ScanTypes<I8>::acc4 acc4;
     typedef typename ScanTypes<I8>::val val;
     // Rows of more than 8 steps: a 64-row tile still pays (one wave per SIMD holds it in the 512 registers
@@ -1291,8 +1314,21 @@ __device__ __forceinline__ void leafscan_chunks(const LeafScanParams &p, const u
         f16x8 qa[QS];
         const size_t qat = (size_t)(qsc >= 0 ? qsc : 0);
         const uint16_t *qrow = Q16 + (DPF_ABLATION(p, 2) ? (qat & 15) : qat) * STRIDE + 8 * g;   // debug 2: all query rows from one hot spot (timing only)
+        if constexpr (COAL) {
+            // quad j reads the query at chunk position j; operand row i16 then holds position pi(i16) = jq
+            const int lj = lane >> 2;
+            const int32_t ql = __shfl(qsc, 4 * (lj & 3) + (lj >> 2));
+            const uint16_t *qr = Q16 + (size_t)(ql >= 0 ? ql : 0) * STRIDE + 8 * (lane & 3);
+            const int src4 = (((lane & 3) << 4) | (lane & 12) | (lane >> 4)) << 2;
+            f16x8 raw[QS];
 #pragma unroll
-        for (int t = 0; t < QS; t++) qa[t] = *(const f16x8 *)(qrow + 32 * t);
+            for (int t = 0; t < QS; t++) raw[t] = *(const f16x8 *)(qr + 32 * t);
+#pragma unroll
+            for (int t = 0; t < QS; t++) qa[t] = operand_from_quads(raw[t], src4);
+        } else {
+#pragma unroll
+            for (int t = 0; t < QS; t++) qa[t] = *(const f16x8 *)(qrow + 32 * t);
+        }
         const float m_tau = dec_f32(__hip_atomic_load(&p.tau[qat], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         const float4 qc = p.qc[qat];
         uint4 qtv = make_uint4(0u, 0u, 0u, 0u);
@@ -1517,9 +1553,8 @@ __device__ __forceinline__ void leafscan_flush_rest(const LeafScanParams &p, con
 #endif
 constexpr int ls16_waves(int ks, int rb, bool i8 = false) { return i8 && ks <= 2 ? LS8_WAVES : ks > 8 && rb == 4 ? 1 : ks >= 8 ? 2 : LS16_WAVES4; }
 
-template <int KS, int METRIC, int RB, bool TAIL, bool I8 = false>
-__global__ __launch_bounds__(256, ls16_waves(KS, RB, I8)) void k_leafscan_f16(LeafScanParams p, const uint16_t *__restrict__ Q16,
-                                                                          const uint16_t *__restrict__ B16)
+template <int KS, int METRIC, int RB, bool TAIL, bool I8, bool COAL>
+__device__ __forceinline__ void leafscan_body(const LeafScanParams &p, const uint16_t *__restrict__ Q16, const uint16_t *__restrict__ B16)
 {
     if (p.gate && (*p.gate != 0) != (p.gate_want != 0)) return;     // the other form of the scan answers this batch
     __shared__ uint4 s_qt[4][TAIL ? 16 : 1];              // the chunk's query tails and their squared norms
@@ -1603,12 +1638,30 @@ __global__ __launch_bounds__(256, ls16_waves(KS, RB, I8)) void k_leafscan_f16(Le
 #pragma unroll
         for (int rb = 0; rb < RB; rb++) {
             if (rb * 16u >= rows && rb > 0) continue;
+            if constexpr (COAL) {
+                // quad j reads row pi(j) of the block whole; the permutation leaves row i16 in operand column i16
+                const int lj = lane >> 2;
+                const int32_t idl = __shfl(id0[rb], 4 * (lj & 3) + (lj >> 2));
+                const uint16_t *row = B16 + (size_t)(idl >= 0 ? idl - row_lo : 0) * STRIDE + 8 * (lane & 3);
+#pragma unroll
+                for (int t = 0; t < KS; t++) xb[rb][t] = *(const f16x8 *)(row + 32 * t);
+            } else {
             const size_t at = (size_t)(id0[rb] >= 0 ? id0[rb] - row_lo : 0);
             const uint16_t *row = B16 + at * STRIDE + 8 * g;
 #pragma unroll
             for (int t = 0; t < KS; t++) xb[rb][t] = *(const f16x8 *)(row + 32 * t);
+            }
             if constexpr (I8) nJ[rb] = rb * 16u + (uint32_t)i16 < rows ? p.slot_nj8[tile_slot0 + rb * 16u + (uint32_t)i16] : 0;
             else nJ[rb] = rb * 16u + (uint32_t)i16 < rows ? p.slot_norm[tile_slot0 + rb * 16u + (uint32_t)i16] : 0.f;
+        }
+        if constexpr (COAL) {
+            const int src4 = (((lane & 3) << 4) | (lane & 12) | (lane >> 4)) << 2;
+#pragma unroll
+            for (int rb = 0; rb < RB; rb++) {
+                if (rb * 16u >= rows && rb > 0) continue;
+#pragma unroll
+                for (int t = 0; t < KS; t++) xb[rb][t] = operand_from_quads(xb[rb][t], src4);
+            }
         }
         int32_t idj[RB];
 #pragma unroll
@@ -1631,10 +1684,24 @@ __global__ __launch_bounds__(256, ls16_waves(KS, RB, I8)) void k_leafscan_f16(Le
         u_after = unit_of(3u * places + (uint32_t)__builtin_amdgcn_readfirstlane((int)pend));
         if (lane == 0) pend = atomicAdd(ctr, 1u);
         small(U0, id0, qs0);
-        leafscan_chunks<KS, METRIC, RB, TAIL, I8>(p, Q16, xb, nJ, idj, rows, nq, lq0, xrm, cxm, qsc, qsn, s_fq[wave], s_fid[wave], s_fv[wave],
+        leafscan_chunks<KS, METRIC, RB, TAIL, I8, COAL>(p, Q16, xb, nJ, idj, rows, nq, lq0, xrm, cxm, qsc, qsn, s_fq[wave], s_fid[wave], s_fv[wave],
                                               s_slot[wave], s_G[wave], s_qid[wave], nbuf, s_xt[wave], s_qt[wave], s_qt2[wave]);
     }
     leafscan_flush_rest(p, s_fq[wave], s_fid[wave], s_fv[wave], nbuf);
+}
+
+template <int KS, int METRIC, int RB, bool TAIL>
+__global__ __launch_bounds__(256, ls16_waves(KS, RB)) void k_leafscan_f16(LeafScanParams p, const uint16_t *__restrict__ Q16,
+                                                                          const uint16_t *__restrict__ B16)
+{
+    leafscan_body<KS, METRIC, RB, TAIL, false, (LS16_COAL != 0) && KS <= 4 && RB == 4>(p, Q16, B16);
+}
+// the int8 form: rows and query rows of KS * 64 bytes
+template <int KS>
+__global__ __launch_bounds__(256, ls16_waves(KS, 4, true)) void k_leafscan_i8(LeafScanParams p, const uint16_t *__restrict__ Q8,
+                                                                              const uint16_t *__restrict__ B8)
+{
+    leafscan_body<KS, 1, 4, false, true, LS8_COAL != 0>(p, Q8, B8);
 }
 
 template <int METRIC, int RB>
@@ -1655,7 +1722,7 @@ static void launch_leafscan_f16_m(const LeafScanParams &p, hipStream_t stream)
     } while (0)
     if constexpr (RB == 4 && METRIC == 1) {
         if (p.i8) {
-#define DPF_LB8(KS) hipLaunchKernelGGL((k_leafscan_f16<KS, 1, 4, false, true>), grid, block, 0, stream, q, q.Q16, q.base16)
+#define DPF_LB8(KS) hipLaunchKernelGGL((k_leafscan_i8<KS>), grid, block, 0, stream, q, q.Q16, q.base16)
             switch (p.ks) {
             case 1: DPF_LB8(1); break;
             case 2: DPF_LB8(2); break;
@@ -1776,18 +1843,22 @@ int leafscan_f16_filter_dim(int dim, int metric)
 // query row's conversion.  The exact k-th best score of the query's seed sample, moved to the safe side by the
 // conversion to fp32 (l2: up, dot: down); l2 stores the radius sqrt(k-th best squared distance) + |q - q~|.  A
 // query with fewer than k seeds starts without a threshold.
+__device__ __forceinline__ void write_tau_value(const TauParams &t, int64_t q, float v, float qn, float qe, int stride)
+{
+    const float c32 = leafscan_c32(stride);
+    t.tau[q] = enc_f32(v);
+    t.qc[q] = make_float4(t.metric == 1 ? 0.5f * qn * (1.0f - c32) : sqrtf(qn) * 1.00001f, qe, qn,
+                          __int_as_float(t.qids ? t.qids[q] : -1));
+}
 __device__ __forceinline__ void write_tau(const TauParams &t, int64_t q, float qn, float qe, int stride)
 {
     // (no seed sample: every query starts without a threshold)
     const int32_t kth_id = t.seed_ids ? t.seed_ids[q * t.k + t.k - 1] : -1;
     const double kth = t.seed_ids ? t.seed_scores[q * t.k + t.k - 1] : 0.0;
-    const float c32 = leafscan_c32(stride);
     float v;
     if (t.metric == 1) v = kth_id < 0 ? HUGE_VALF : sqrtf(fmaxf((float)kth, 0.f) * 1.000001f) * 1.000001f + qe;
     else v = kth_id < 0 ? -HUGE_VALF : (float)kth - fabsf((float)kth) * 1e-6f - 1e-30f;
-    t.tau[q] = enc_f32(v);
-    t.qc[q] = make_float4(t.metric == 1 ? 0.5f * qn * (1.0f - c32) : sqrtf(qn) * 1.00001f, qe, qn,
-                          __int_as_float(t.qids ? t.qids[q] : -1));
+    write_tau_value(t, q, v, qn, qe, stride);
 }
 
 // fp32 rows (stride src_stride floats, `dim` meaningful) -> fp16 rows of dst_stride elements (a
@@ -1899,6 +1970,166 @@ __global__ __launch_bounds__(256) void k_rows_to_f16_long(const float *__restric
         if (TAU) write_tau(tp, r, ss, er, dst_stride);
     }
 }
+// ---------------------------------------------------------------------------
+// k_seed_radius: first thresholds of an l2 batch from the fp16 copies
+// ---------------------------------------------------------------------------
+// The scan only needs an UPPER bound of each query's k-th best distance to start from, and the fp16 copies give
+// one at half the bytes of the fp32 rows (or less): with S = |q~ - x~|^2 (fp32 sum of squared differences, all terms
+// non-negative: relative error at most (terms + 16) 2^-24), sqrt(exact distance) <= sqrt(S) + |x - x~| + |q - q~|.
+// One wave per query, 4 lanes per seed row (a lane reads the 16-byte piece 4 t + c of every 32-dimension step t: the
+// four lanes of a row read 64 consecutive bytes), 32 rows in flight; the wave keeps the k smallest
+// u = sqrt(S) + |x - x~| of distinct ids sorted across its lanes; radius R = k-th smallest u + 2 |q - q~|
+// (what the scan's threshold word holds: R >= sqrt(k-th best squared distance) + |q - q~|).  Fewer than k seeds: no
+// threshold.  Also writes the per-query record of the scan (as the TAU form of the row conversion does).
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ float sqdiff8(const uint4 &a, const uint4 &b, float acc)
+{
+    const f16x8_t x = __builtin_bit_cast(f16x8_t, a), y = __builtin_bit_cast(f16x8_t, b);
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const float d = (float)x[e] - (float)y[e];
+        acc = fmaf(d, d, acc);
+    }
+    return acc;
+}
+__device__ __forceinline__ void topk_insert_f(float s, int32_t id, float &ls, int32_t &lid, int K, int lane)
+{
+    const bool shift = (lane < K) && (s < ls || (s == ls && id < lid));
+    const unsigned long long mask = __ballot(shift);
+    if (mask == 0) return;
+    if (__ballot((lane < K) && lid == id)) return;        // the same row reached through two buckets: once
+    const int pos = __ffsll((long long)mask) - 1;
+    const float ps = __shfl_up(ls, 1);
+    const int32_t pid = __shfl_up(lid, 1);
+    if (lane == pos) { ls = s; lid = id; }
+    else if (lane > pos && lane < K) { ls = ps; lid = pid; }
+}
+
+struct SeedRadiusParams {
+    const int32_t *cand;      // [nq][cand_stride] seed ids
+    const int32_t *cnt;       // [nq]
+    int64_t cand_stride;
+    const uint16_t *Q16, *B16;   // fp16 rows of ks * 32 elements
+    const float *q_norm, *q_err; // [nq] squared norms and rounding distances of the query copies
+    const float *b_err;          // [rows] rounding distances of the row copies
+    const uint4 *q_tail, *b_tail; // tails of cut rows (nullptr: whole rows)
+    int64_t row_begin, row_end;
+    int32_t ks;
+    TauParams tau;
+};
+
+template <int KSQ>   // > 0: ks == KSQ, the query row stays in registers; 0: any ks, query pieces re-read (they stay in L1)
+__global__ __launch_bounds__(256) void k_seed_radius(SeedRadiusParams p, int64_t nq)
+{
+    constexpr int UR = 2;
+    const int lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    const int grp = lane >> 2, gl = lane & 3;
+    const int K = p.tau.k;
+    const int ks = KSQ > 0 ? KSQ : p.ks;
+    const uint4 *qrow = (const uint4 *)(p.Q16 + (size_t)q * ks * 32) + gl;
+    uint4 qv[KSQ > 0 ? KSQ : 1];
+    if (KSQ > 0) {
+#pragma unroll
+        for (int t = 0; t < KSQ; t++) qv[t] = qrow[4 * t];
+    }
+    uint4 qt = make_uint4(0u, 0u, 0u, 0u);
+    if (p.q_tail) qt = p.q_tail[q];
+    float ls = HUGE_VALF;
+    int32_t lid = 0x7fffffff;
+    int32_t cnt = p.cnt[q];
+    if (cnt > p.cand_stride) cnt = (int32_t)p.cand_stride;
+    const int32_t *cand = p.cand + q * p.cand_stride;
+    // S <= computed (1 + (terms + 16) 2^-24): 32 ks elements per lane and the tail, three additions across and inside lanes
+    const float up = 1.0f + (float)(32 * ks + 8 + 16) * 6.3e-8f;
+
+    int32_t idn[UR];
+#pragma unroll
+    for (int u = 0; u < UR; u++) idn[u] = u * 16 + grp < cnt ? cand[u * 16 + grp] : -1;
+    for (int32_t b0 = 0; b0 < cnt; b0 += 16 * UR) {
+        int32_t id[UR];
+        float acc[UR], xe[UR];
+#pragma unroll
+        for (int u = 0; u < UR; u++) {
+            id[u] = idn[u];
+            if (!(id[u] >= p.row_begin && id[u] < p.row_end)) id[u] = -1;
+        }
+#pragma unroll
+        for (int u = 0; u < UR; u++) {
+            const int32_t idx = b0 + 16 * UR + u * 16 + grp;
+            idn[u] = idx < cnt ? cand[idx] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < UR; u++) {
+            const size_t at = (size_t)(id[u] >= 0 ? id[u] - p.row_begin : 0);
+            const uint4 *row = (const uint4 *)(p.B16 + at * ks * 32) + gl;
+            float a = 0.f;
+            if (KSQ > 0) {
+                uint4 x[KSQ > 0 ? KSQ : 1];
+#pragma unroll
+                for (int t = 0; t < KSQ; t++) x[t] = row[4 * t];
+#pragma unroll
+                for (int t = 0; t < KSQ; t++) a = sqdiff8(qv[t], x[t], a);
+            } else {
+                for (int t = 0; t < ks; t += 4) {
+                    uint4 x[4], y[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) { x[i] = t + i < ks ? row[4 * (t + i)] : make_uint4(0u, 0u, 0u, 0u); y[i] = t + i < ks ? qrow[4 * (t + i)] : make_uint4(0u, 0u, 0u, 0u); }
+#pragma unroll
+                    for (int i = 0; i < 4; i++) a = sqdiff8(y[i], x[i], a);
+                }
+            }
+            if (p.b_tail && gl == 0) a = sqdiff8(qt, p.b_tail[at], a);
+            xe[u] = p.b_err[at];
+            acc[u] = a;
+        }
+#pragma unroll
+        for (int u = 0; u < UR; u++) {
+            float a = acc[u];
+            a += __shfl_xor(a, 1);
+            a += __shfl_xor(a, 2);
+            const float uu = sqrtf(a * up) * 1.000001f + xe[u];
+            const float kth = __shfl(ls, K - 1);
+            const int32_t kth_id = __shfl(lid, K - 1);
+            const bool cand_ok = gl == 0 && id[u] >= 0 && (uu < kth || (uu == kth && id[u] < kth_id));
+            unsigned long long m = __ballot(cand_ok);
+            while (m) {
+                const int src = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                topk_insert_f(__shfl(uu, src), __shfl(id[u], src), ls, lid, K, lane);
+            }
+        }
+    }
+    const float kth = __shfl(ls, K - 1);
+    const int32_t kth_id = __shfl(lid, K - 1);
+    if (lane == 0) {
+        const float qe = p.q_err[q];
+        const float v = kth_id == 0x7fffffff ? HUGE_VALF : (kth + 2.0f * qe) * 1.000002f;
+        write_tau_value(p.tau, q, v, p.q_norm[q], qe, ks * 32);
+    }
+}
+
+void launch_seed_radius(const int32_t *cand, const int32_t *cnt, int64_t cand_stride, const uint16_t *Q16, const uint16_t *B16, int ks,
+                        const float *q_norm, const float *q_err, const float *b_err, const uint4 *q_tail, const uint4 *b_tail,
+                        int64_t row_begin, int64_t row_end, const TauParams &tau, int64_t nq, hipStream_t stream)
+{
+    if (nq <= 0) return;
+    SeedRadiusParams p;
+    p.cand = cand; p.cnt = cnt; p.cand_stride = cand_stride; p.Q16 = Q16; p.B16 = B16; p.q_norm = q_norm; p.q_err = q_err;
+    p.b_err = b_err; p.q_tail = b_tail ? q_tail : nullptr; p.b_tail = q_tail ? b_tail : nullptr;
+    p.row_begin = row_begin; p.row_end = row_end; p.ks = ks; p.tau = tau;
+    const dim3 grid((unsigned)((nq + 3) / 4)), block(256);
+    switch (ks) {
+    case 1: hipLaunchKernelGGL((k_seed_radius<1>), grid, block, 0, stream, p, nq); break;
+    case 2: hipLaunchKernelGGL((k_seed_radius<2>), grid, block, 0, stream, p, nq); break;
+    case 3: hipLaunchKernelGGL((k_seed_radius<3>), grid, block, 0, stream, p, nq); break;
+    case 4: hipLaunchKernelGGL((k_seed_radius<4>), grid, block, 0, stream, p, nq); break;
+    case 8: hipLaunchKernelGGL((k_seed_radius<8>), grid, block, 0, stream, p, nq); break;
+    default: hipLaunchKernelGGL((k_seed_radius<0>), grid, block, 0, stream, p, nq); break;
+    }
+}
+
 void launch_rows_to_f16(const float *src, int64_t src_stride, int dim, int64_t n, uint16_t *dst, int dst_stride,
                          float *norms, float *errs, hipStream_t stream, const TauParams *tau, int dim_all, uint4 *tails)
 {

@@ -1123,6 +1123,8 @@ def test_int8_copy_only_where_the_rows_allow_it():
     ix.query_topk(pick, Q, steps=1, k=10)
     assert ix.stats()["last_scan_int8"] == 0
     ix.close()
+    Xf = X + 3000.0                                                # beyond the integers fp16 holds exactly
+    check(Xf, False)
     # more than 256 dimensions: no int8 rows
     p2, X2, Q2, pick2 = _integer_problem(2000, 20, 300, 0, seed=4, bucket_overflow=50, table_num=2, permutation_num=1)
     ix = DpfIndex(p2, metric="l2")
@@ -1130,3 +1132,30 @@ def test_int8_copy_only_where_the_rows_allow_it():
     assert ix.stats()["base8_bytes"] == 0
     ix.close()
     slow.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim", [33, 100, 128, 200, 300, 768, 1000])
+def test_first_radii_from_fp16_copies_or_exact_seeds(dim):
+    # l2 handles take each query's first radius from the fp16 copies of its seed rows (an upper bound of the k-th best
+    # distance); DPF_OPT_EXACT_SEEDS scores the seeds exactly from the fp32 rows instead: same answers either way, and
+    # about the same number of rows forwarded (the bound is loose only by the measured rounding distances)
+    n, nq = (8000, 120) if dim <= 300 else (3000, 60)
+    params, X, Q, pick = make_problem(n=n, nq=nq, dim=dim, bucket_overflow=50, table_num=2, permutation_num=2, n_clusters=8)
+    half = DpfIndex(params, metric="l2")
+    exact = DpfIndex(params, metric="l2")
+    slow = DpfIndex(dict(params, flags=2), metric="l2")
+    for ix in (half, exact, slow):
+        ix.fit(X)
+    exact.set_option("exact_seeds", 1)
+    for steps, k in ((1, 10), (0, 1), (3, 64)):
+        hi_, hs = half.query_topk(pick, Q, steps=steps, k=k)
+        ei, es = exact.query_topk(pick, Q, steps=steps, k=k)
+        si, ss = slow.query_topk(pick, Q, steps=steps, k=k)
+        assert half.stats()["last_path"] == 1 and exact.stats()["last_path"] == 1
+        assert np.array_equal(hi_, si) and np.array_equal(hs, ss, equal_nan=True)
+        assert np.array_equal(ei, si) and np.array_equal(es, ss, equal_nan=True)
+        f_half, f_exact = half.stats()["last_forwarded"], exact.stats()["last_forwarded"]
+        assert f_half <= 1.2 * f_exact + 4 * nq, (f_half, f_exact)
+    for ix in (half, exact, slow):
+        ix.close()

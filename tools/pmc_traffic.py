@@ -60,8 +60,23 @@ rec = {
                   "served by the Infinity Cache are included",
     "traffic_bytes_per_launch": 2.0 * f_raw + w,
 }
+INT8_DENSE_PEAK_TOPS = 5000.0        # MI355X dense int8 matrix peak
 mops = mfma.get((name, "SQ_INSTS_VALU_MFMA_MOPS_F16"))
-if mops:
+mops8 = mfma.get((name, "SQ_INSTS_VALU_MFMA_MOPS_I8"))
+if mops8 and mops8[0] > 0 and not (mops and mops[0] > 0):
+    ops = mops8[0] * 512.0
+    busy = mfma.get((name, "SQ_VALU_MFMA_BUSY_CYCLES"), (0.0, 0))[0]
+    rec.update({
+        "mfma_flops_per_launch": ops,
+        "mfma_instructions_per_launch": mfma.get((name, "SQ_INSTS_MFMA"), (0.0, 0))[0],
+        "mfma_busy_cycles_per_launch": busy,
+        "mfma_tflops": ops / avg_ns / 1e3,
+        "mfma_util": ops / avg_ns / 1e3 / INT8_DENSE_PEAK_TOPS,
+        "mfma_busy_share_of_simd_cycles": busy / (avg_ns * CLOCK_GHZ * SIMDS),
+        "mfma_util_definition": "SQ_INSTS_VALU_MFMA_MOPS_I8 x 512 op / kernel-trace duration / 5000 TOP/s (dense int8 peak); "
+                                "busy share = SQ_VALU_MFMA_BUSY_CYCLES / (duration x 2.4 GHz x 1024 SIMDs)",
+    })
+elif mops:
     flops = mops[0] * 512.0
     busy = mfma.get((name, "SQ_VALU_MFMA_BUSY_CYCLES"), (0.0, 0))[0]
     rec.update({

@@ -10,7 +10,8 @@ for W in c2 c3 c4 c5; do
   test -d gpurun_out/pmc_$W/fetch || continue
   case $W in c5) N=1250000; Q=12500 ;; *) N=1000000; Q=10000 ;; esac
   case $W in c2) S=0 ;; *) S=1 ;; esac
-  python3 tools/pmc_traffic.py $W k_leafscan_f16 $W $N $Q $S > profiles/${T}_${W}_k_leafscan_f16_pmc_traffic.json
+  K=k_leafscan_f16; test $W = c4 && K=k_leafscan_i8     # (integer-valued rows: the int8 form of the scan runs)
+  python3 tools/pmc_traffic.py $W $K $W $N $Q $S > profiles/${T}_${W}_${K}_pmc_traffic.json
   cpif "$(find gpurun_out/pmc_$W/kt -name 'kt_kernel_stats.csv' | head -1)" profiles/${T}_${W}_kernel_stats.csv
   grep '^{"metric"' gpurun_out/pmc_$W/kt.log | tail -1 > profiles/${T}_${W}_bench_under_rocprof.json
 done
