@@ -29,6 +29,15 @@ object Dpf {
   val OptSeedSample = 5
   val OptShortRerank = 6
   val OptProjectionMinRows = 7
+  val OptScanPasses = 8
+  val OptEarlyPassPermille = 9
+  val OptExactSeeds = 10
+  // DPF_FLAG_* of dpf_config.flags
+  val FlagHashOnly = 1
+  val FlagGatherOnly = 2
+  val FlagHostForest = 4
+  val FlagFullFilter = 8
+  val FlagNoInt8 = 16
 
   /** The int32 fields of `dpf_config`, in declaration order (checked against include/dpf.h by tests/test_jni_shim.py). */
   val ConfigIntFields: Array[String] = Array(
