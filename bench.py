@@ -196,6 +196,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-recall", action="store_true")
     ap.add_argument("--no-host-to-host", action="store_true")
+    ap.add_argument("--no-gather-check", action="store_true",
+                    help="skip the untimed run of the same batch through the per-query gather rerank (its candidate lists need "
+                         "4 bytes per visited id: too much at 10M base / 100k queries)")
     ap.add_argument("--in-flight", type=int, default=1, choices=[1, 2],
                     help="2: also measure the throughput with two batches in flight on one GPU (reported as value_two_in_flight)")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
@@ -378,7 +381,7 @@ def main():
         dist.barrier()
 
     gather = None
-    if rank == 0 and world == 1 and st["last_path"] == 1:
+    if rank == 0 and world == 1 and st["last_path"] == 1 and not args.no_gather_check:
         # the per-query gather rerank on the same batch (untimed): its bytes are the classic rerank roofline
         # (every de-duplicated candidate row once per query), and it yields the de-duplicated candidate count
         from similaritysearchbyrdf_amd._lib import DpfIndex
@@ -402,6 +405,24 @@ def main():
                   "algorithmic_bytes_per_launch": by, "ms_per_launch": float(np.mean(g_ms[1:])),
                   "unique_candidates_per_query": gst["last_unique_candidates"] / nq, "same_ids_as_timed_path": same}
         gi.close()
+
+    sampled = None
+    if rank == 0 and world == 1 and st["last_path"] == 1 and args.no_gather_check:
+        # instead: a few queries of batch 0 through the gather path of the same handle (the entry point that takes that
+        # path within fixed buffers), compared with what the timed path returned for them
+        m = int(min(nq, 1024, max(1, 5_000_000 // max(1, int(st["last_raw_candidates"] / nq)))))
+        s_ids = torch.empty((m, k), dtype=torch.int32, device=dev)
+        s_sc = torch.empty((m, k), dtype=torch.float64, device=dev)
+        ix.query_topk_device_static(dqid.data_ptr(), dQ.data_ptr(), m, steps, k, s_ids.data_ptr(), s_sc.data_ptr(),
+                                    torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        sampled = {"queries": m, "same_ids": bool(np.array_equal(s_ids.cpu().numpy(), final_ids[:m])),
+                   "same_scores": bool(np.array_equal(s_sc.cpu().numpy(), final_sc[:m], equal_nan=True)),
+                   "what": "the first queries of batch 0 through the per-query gather path (exact fp64 scores of the whole "
+                           "candidate Set) against the timed path's answers"}
+        run_batch(0)                      # the statistics below describe the timed path again
+        fence()
+        st = ix.stats()
 
     large = None
     if (rank == 0 and world == 1 and args.workload == "c3" and n == 1_000_000 and args.large_table_rows > n
@@ -479,6 +500,8 @@ def main():
             out["two_in_flight"] = two
         if gather is not None:
             out["roofline_gather_rerank"] = gather
+        if sampled is not None:
+            out["sampled_gather_check"] = sampled
         if large is not None:
             out["roofline_large_table"] = large
         if world == 1 and not args.no_cpu_baseline:

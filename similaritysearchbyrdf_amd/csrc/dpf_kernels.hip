@@ -362,10 +362,42 @@ __global__ __launch_bounds__(1024) void k_probe(ProbeParams p)
                         if (leaf[x][k] == own && (same & ((1ull << i) - 1ull) & 0xffffffffull)) leaf[x][k] = NO_LEAF;
                         own_hit[x][k] = leaf[x][k] != NO_LEAF && leaf[x][k] == own && sw[x][k] == part[x];
                     }
+                if constexpr (MODE == 0) {
+                    // the four buckets of a lane together: their bounds in one round of loads, then the four
+                    // counter updates in flight at once (one after the other they were four dependent round trips)
+                    uint32_t lb[4], le[4], place[4];
+#pragma unroll
+                    for (int v = 0; v < 4; v++) {
+                        const uint32_t lf = leaf[v >> 1][v & 1];
+                        lb[v] = 0; le[v] = 0;
+                        if (lf != NO_LEAF) { lb[v] = p.leaf_off[lf]; le[v] = p.leaf_off[lf + 1]; }
+                    }
+#pragma unroll
+                    for (int v = 0; v < 4; v++) {
+                        raw_local += le[v] - lb[v];
+                        place[v] = 0;
+                        if (p.lq_cnt && le[v] > lb[v]) place[v] = atomicAdd(&p.lq_cnt[leaf[v >> 1][v & 1]], 1u);
+                    }
+                    if (p.lq_cnt && p.q_leaves) {
+                        // one LDS counter update per lane for all of its buckets
+                        const uint32_t mine = (le[0] > lb[0]) + (le[1] > lb[1]) + (le[2] > lb[2]) + (le[3] > lb[3]);
+                        uint32_t pos = mine ? atomicAdd(&s_nleaf, mine) : 0u;
+#pragma unroll
+                        for (int v = 0; v < 4; v++) {
+                            if (le[v] > lb[v]) {
+                                // top bit: the bucket the query itself would be stored in (same sub-index, same path)
+                                if (pos < (uint32_t)p.q_leaf_cap)
+                                    p.q_leaves[q * p.q_leaf_cap + pos] = make_uint2(leaf[v >> 1][v & 1], place[v] | (own_hit[v >> 1][v & 1] ? 0x80000000u : 0u));
+                                pos++;
+                            }
+                        }
+                    }
+                } else {
 #pragma unroll
                 for (int x = 0; x < 2; x++) {
                     take(leaf[x][0], own_hit[x][0]);
                     take(leaf[x][1], own_hit[x][1]);
+                }
                 }
             }
         }
@@ -450,12 +482,22 @@ __global__ __launch_bounds__(256) void k_fill_lists(ProbeParams p)
     if (tid == 0) { s_seed = 0; s_nown = 0; }
     __syncthreads();
     const uint2 *mine = p.q_leaves + q * p.q_leaf_cap;
-    for (int j = tid; j < n; j += 256) {
-        const uint2 lp = mine[j];                         // {bucket, place in the bucket's list | own-bucket flag}
-        p.leaf_queries[p.lq_off32[lp.x] + (lp.y & 0x7fffffffu)] = (int32_t)q;
-        if (lp.y & 0x80000000u) {
-            const uint32_t at = atomicAdd(&s_nown, 1u);
-            if (at < 256u) s_own[at] = lp.x;
+    for (int j0 = tid; j0 < n; j0 += 1024) {
+        // four entries per thread and round: the entries, then their buckets' list offsets, in flight together
+        uint2 lp[4];                                      // {bucket, place in the bucket's list | own-bucket flag}
+        uint32_t off[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) lp[u] = j0 + 256 * u < n ? mine[j0 + 256 * u] : make_uint2(0u, 0u);
+#pragma unroll
+        for (int u = 0; u < 4; u++) off[u] = j0 + 256 * u < n ? p.lq_off32[lp[u].x] : 0u;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (j0 + 256 * u >= n) continue;
+            p.leaf_queries[off[u] + (lp[u].y & 0x7fffffffu)] = (int32_t)q;
+            if (lp[u].y & 0x80000000u) {
+                const uint32_t at = atomicAdd(&s_nown, 1u);
+                if (at < 256u) s_own[at] = lp[u].x;
+            }
         }
     }
     __syncthreads();
