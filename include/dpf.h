@@ -178,7 +178,10 @@ int dpf_hash_batch(dpf_index *ix, const void *Q, int64_t nq, int32_t *hashes, in
 /* DensevectorRDFInit.NewMultiThreadQueryBatch(queryArray, denseVectorArray, steps, _)
  * (Dense:335-360): per query the Set of similar ids as a sorted unique list,
  * restricted to [row_begin, row_end).  cand_offsets[nq+1] is caller memory;
- * *cand_ids is allocated by the library, release with dpf_free.  Host pointers. */
+ * *cand_ids comes from the library: normally the handle's own pinned host buffer, which the
+ * handle's NEXT dpf_query_batch overwrites and dpf_destroy releases (copy what must outlive that;
+ * the JNI shim copies into Java arrays at once); a malloc'd block when pinned memory cannot be had.
+ * Either way pass it to dpf_free when done (a no-op for the handle's own buffer).  Host pointers. */
 int dpf_query_batch(dpf_index *ix, const int32_t *qids, const void *Q, int64_t nq, int32_t steps,
                     int64_t *cand_offsets, int32_t **cand_ids);
 void dpf_free(void *p);

@@ -253,8 +253,9 @@ class DpfIndex:
         self._check(self.L_.dpf_hash_batch(self.h, Q.ctypes.data, nq, _ip(h), _ip(p)))
         return h, p
 
-    def query_batch(self, qids, Q, steps=0):
-        """NewMultiThreadQueryBatch -> (offsets [nq+1] int64, ids int32)."""
+    def query_batch(self, qids, Q, steps=0, copy=True):
+        """NewMultiThreadQueryBatch -> (offsets [nq+1] int64, ids int32).  copy=False returns the ids as a view of the
+        handle's own result buffer: valid until the handle's next query_batch (or close)."""
         Q = self._rows(Q)
         nq = Q.shape[0]
         qids = _i32(qids)
@@ -263,7 +264,9 @@ class DpfIndex:
         self._check(self.L_.dpf_query_batch(self.h, _ip(qids), Q.ctypes.data, nq, steps,
                                             offsets.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(pids)))
         total = int(offsets[nq])
-        ids = np.ctypeslib.as_array(pids, shape=(max(total, 1),))[:total].copy()
+        ids = np.ctypeslib.as_array(pids, shape=(max(total, 1),))[:total]
+        if copy:
+            ids = ids.copy()
         self.L_.dpf_free(pids)
         return offsets, ids
 

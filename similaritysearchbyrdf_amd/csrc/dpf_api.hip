@@ -53,6 +53,10 @@ static_assert(SCRATCH_OFF_ARENA % 256 == 0 && SCRATCH_OFF_CNT % 256 == 0 && SCRA
 constexpr int SCRATCH_MAX_DEVICES = 64;
 void *g_scratch_ptr[SCRATCH_MAX_DEVICES] = {nullptr};
 std::mutex g_scratch_mutex;
+// result buffers of dpf_query_batch that belong to a handle (pinned host memory, reused from call to call): dpf_free
+// leaves these alone
+std::mutex g_results_mutex;
+std::vector<void *> g_handle_results;
 
 }  // namespace
 
@@ -178,6 +182,9 @@ struct dpf_index {
     int64_t prev_units = -1;                 // work units of the handle's last bucket-major batch (-1: none yet)
     unsigned long long *d_short_hash = nullptr;
     int64_t *pinned = nullptr;                        // host-pinned scratch (12 x int64)
+    int32_t *h_sets = nullptr;                        // dpf_query_batch's result lists: pinned host memory, grown as needed
+    size_t h_sets_cap = 0;
+    DevBuf ws_compact;                                // the same lists packed back to back on the device
     bool sizes_carried = false;                       // a bucket-major batch has sized leaf_queries[] / units[] already
     hipEvent_t ev[6]{};
     int last_path = 0;
@@ -322,6 +329,15 @@ extern "C" void dpf_destroy(dpf_index *ix)
     if (ix->d_proj_counters) (void)hipFree(ix->d_proj_counters);
     { DevBuf *pb[] = {&ix->d_fn_norm, &ix->ws_proj_codes, &ix->ws_proj_norm, &ix->ws_proj_flag, &ix->ws_proj_rows}; for (DevBuf *b : pb) b->release(); }
     if (ix->pinned) (void)hipHostFree(ix->pinned);
+    if (ix->h_sets) {
+        {
+            std::lock_guard<std::mutex> lock(g_results_mutex);
+            for (size_t i = 0; i < g_handle_results.size(); i++)
+                if (g_handle_results[i] == ix->h_sets) { g_handle_results.erase(g_handle_results.begin() + i); break; }
+        }
+        (void)hipHostFree(ix->h_sets);
+    }
+    ix->ws_compact.release();
     for (int i = 0; i < 6; i++) if (ix->ev[i]) (void)hipEventDestroy(ix->ev[i]);
     for (int i = 0; i < 6; i++) if (ix->ev_scan[i]) (void)hipEventDestroy(ix->ev_scan[i]);
     DevBuf *more[] = {&ix->ws_emit_ucnt, &ix->ws_emit_v, &ix->ws_leaf_units, &ix->ws_unit_off, &ix->ws_q_leaves, &ix->ws_q_leaf_cnt, &ix->d_leaf_tile0, &ix->ws_units, &ix->d_tiles, &ix->ws_lq_off, &ix->ws_lq_cursor, &ix->ws_leaf_queries,
@@ -1558,22 +1574,55 @@ extern "C" int dpf_query_batch(dpf_index *ix, const int32_t *qids, const void *Q
     launch_scan_i32(ix->ws_cnt.as<int32_t>(), nq, ix->ws_misc.as<int64_t>(), nullptr);
     HIPCHECK(ix, hipMemcpy(cand_offsets, ix->ws_misc.p, (size_t)(nq + 1) * 8, hipMemcpyDeviceToHost));
     const int64_t total = cand_offsets[nq];
-    int32_t *host = (int32_t *)malloc((size_t)std::max<int64_t>(total, 1) * 4);
+    // The lists land in a pinned host buffer the handle keeps and grows (at c3 a batch's Sets are 2.9 GB of ids: into
+    // pinned memory they arrive at the link's rate, into fresh pageable memory at a tenth of it).  When pinned memory is
+    // not to be had the lists go to a malloc'd block the caller owns, as before.
+    const size_t bytes = (size_t)std::max<int64_t>(total, 1) * 4;
+    int32_t *host = nullptr;
+    bool handle_owned = false;
+    if (bytes > ix->h_sets_cap) {
+        std::lock_guard<std::mutex> lock(g_results_mutex);
+        if (ix->h_sets) {
+            for (size_t i = 0; i < g_handle_results.size(); i++)
+                if (g_handle_results[i] == ix->h_sets) { g_handle_results.erase(g_handle_results.begin() + i); break; }
+            (void)hipHostFree(ix->h_sets);
+            ix->h_sets = nullptr; ix->h_sets_cap = 0;
+        }
+        void *q = nullptr;
+        const size_t want = bytes + bytes / 4 + 4096;
+        if (hipHostMalloc(&q, want, hipHostMallocDefault) == hipSuccess) {
+            ix->h_sets = (int32_t *)q; ix->h_sets_cap = want;
+            g_handle_results.push_back(q);
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    if (ix->h_sets && bytes <= ix->h_sets_cap) { host = ix->h_sets; handle_owned = true; }
+    else host = (int32_t *)malloc(bytes);
     if (!host) return fail(ix, DPF_ENOMEM, "dpf_query_batch: out of host memory");
     if (total > 0) {
-        DevBuf dst;
-        hipError_t e = dst.ensure((size_t)total * 4);
-        if (e != hipSuccess) { free(host); ix->err = hipGetErrorString(e); return DPF_EHIP; }
-        launch_compact(ix->ws_arena.as<int32_t>(), ix->ws_off.as<int64_t>(), ix->ws_cnt.as<int32_t>(), ix->ws_misc.as<int64_t>(), dst.as<int32_t>(), nq, nullptr);
-        e = hipMemcpy(host, dst.p, (size_t)total * 4, hipMemcpyDeviceToHost);
-        dst.release();
-        if (e != hipSuccess) { free(host); ix->err = hipGetErrorString(e); return DPF_EHIP; }
+        hipError_t e = ix->ws_compact.ensure((size_t)total * 4);
+        if (e == hipSuccess) {
+            launch_compact(ix->ws_arena.as<int32_t>(), ix->ws_off.as<int64_t>(), ix->ws_cnt.as<int32_t>(), ix->ws_misc.as<int64_t>(),
+                           ix->ws_compact.as<int32_t>(), nq, nullptr);
+            e = hipMemcpy(host, ix->ws_compact.p, (size_t)total * 4, hipMemcpyDeviceToHost);
+        }
+        if (e != hipSuccess) { if (!handle_owned) free(host); ix->err = hipGetErrorString(e); return DPF_EHIP; }
     }
     *cand_ids = host;
     return DPF_OK;
 }
 
-extern "C" void dpf_free(void *p) { free(p); }
+extern "C" void dpf_free(void *p)
+{
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lock(g_results_mutex);
+        for (void *q : g_handle_results)
+            if (q == p) return;                           // a handle's own result buffer: reused by its next call
+    }
+    free(p);
+}
 
 extern "C" int dpf_rerank(dpf_index *ix, const void *Q, int64_t nq, const int64_t *cand_offsets,
                           const int32_t *cand_ids, int32_t k, int32_t *ids, double *scores)

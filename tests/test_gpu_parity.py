@@ -1159,3 +1159,25 @@ def test_first_radii_from_fp16_copies_or_exact_seeds(dim):
         assert f_half <= 1.2 * f_exact + 4 * nq, (f_half, f_exact)
     for ix in (half, exact, slow):
         ix.close()
+
+
+@pytest.mark.gpu
+def test_set_lists_come_back_in_the_handles_own_buffer():
+    # dpf_query_batch hands its lists over in a pinned host buffer the handle keeps: the next call reuses it (grown when
+    # a batch needs more), dpf_free leaves it alone, and a copy taken before the next call stays what it was
+    params, X, Q, pick = make_problem(n=5000, nq=64, dim=48, bucket_overflow=40, table_num=2, permutation_num=2)
+    orc, gpu = both(params, X)
+    Q64 = Q.astype(np.float64)
+    o1, v1 = gpu.query_batch(pick, Q, steps=0, copy=False)
+    keep = v1.copy()
+    at1 = v1.ctypes.data
+    o2, v2 = gpu.query_batch(pick, Q, steps=1, copy=False)          # smaller or equal lists fit the same buffer ...
+    assert o2[-1] >= o1[-1]
+    o3, v3 = gpu.query_batch(pick[:8], Q[:8], steps=0, copy=False)
+    assert v3.ctypes.data == v2.ctypes.data
+    assert_same_sets((o3, v3.copy()), orc.query_batch(pick[:8], Q64[:8], steps=0, threads=2, mode=1))
+    assert_same_sets((o1, keep), orc.query_batch(pick, Q64, steps=0, threads=2, mode=1))
+    o4, v4 = gpu.query_batch(pick, Q, steps=3)                        # ... larger ones make it grow; the default is a copy
+    assert_same_sets((o4, v4), orc.query_batch(pick, Q64, steps=3, threads=2, mode=1))
+    assert at1 != 0
+    gpu.close()
