@@ -1181,3 +1181,29 @@ def test_set_lists_come_back_in_the_handles_own_buffer():
     assert_same_sets((o4, v4), orc.query_batch(pick, Q64, steps=3, threads=2, mode=1))
     assert at1 != 0
     gpu.close()
+
+
+@pytest.mark.gpu
+def test_int8_scan_on_row_table_and_subindex_shards():
+    # the int8 copy follows a handle's shard: row shards hold int8 rows of their own rows only (each with its own
+    # window), table and sub-index shards scan their part of the forest; every shard's answer is the gather path's
+    n, nq, dim = 9000, 80, 128
+    params, X, Q, pick = _integer_problem(n, nq, dim, 0, seed=11, bucket_overflow=50, table_num=2, permutation_num=2)
+    X[:4000] = np.minimum(X[:4000], 200.0)                         # the first row shard's window ends below the second's
+    shards = [dict(row_begin=0, row_end=4000), dict(row_begin=4000, row_end=-1), dict(table_begin=1, table_end=3),
+              dict(subindex_group=1, subindex_groups=3)]
+    for kw in shards:
+        fast = DpfIndex(params, metric="l2", **kw)
+        slow = DpfIndex(dict(params, flags=2), metric="l2", **kw)
+        fast.fit(X)
+        slow.fit(X)
+        rows = (4000 if kw.get("row_end") == 4000 else 5000) if "row_begin" in kw else n
+        assert fast.stats()["base8_bytes"] == rows * 128
+        for steps in (1, 2):
+            fi, fs = fast.query_topk(pick, Q, steps=steps, k=10)
+            st = fast.stats()
+            assert st["last_path"] == 1 and st["last_scan_int8"] == 1, kw
+            si, ss = slow.query_topk(pick, Q, steps=steps, k=10)
+            assert np.array_equal(fi, si) and np.array_equal(fs, ss, equal_nan=True), kw
+        fast.close()
+        slow.close()
