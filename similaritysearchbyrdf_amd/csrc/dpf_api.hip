@@ -196,7 +196,8 @@ struct dpf_index {
     int32_t probe_mode = DPF_PROBE_FLIPS;             // dpf_set_probe_mode
     unsigned char *scratch_ptr = nullptr;             // this device's copy of the static scratch array
     // dpf_set_option values (0 / default = the library's own choice)
-    int32_t opt_emit_cap = 0, opt_bucket_list_cap = 0, opt_first_permille = 100, opt_seed_cap = 256;
+    int32_t opt_emit_cap = 0, opt_bucket_list_cap = 0, opt_first_permille = 100, opt_seed_cap = -1;   // seed sample: -1 = by the forest's bucket sizes
+    int32_t auto_seed_cap = 256;             // what -1 stands for, set when the forest is built (seed_sample_for)
     int32_t opt_scan_passes = 0, opt_early_permille = 40;   // passes: 0 = by row length (3 from 16 steps on), 2 or 3
     bool opt_sync_sizes = false, opt_short_rerank = true, opt_exact_seeds = false;
     int64_t opt_projection_min_rows = 4096;           // batches of at least this many vectors hash on the matrix cores (0: never)
@@ -484,6 +485,26 @@ static int hash_rows(dpf_index *ix, const void *X, int64_t stride, int64_t n, in
     return DPF_OK;
 }
 
+// The seed sample a handle draws per query when none is pinned.  The first thresholds come from the k-th best of the
+// sample, which is taken from the query's own buckets (one per probed table); how well it stands for them depends on
+// how many rows those buckets hold.  With m = the size-biased mean bucket size (the expected size of the bucket a
+// stored row - or a query near one - falls into) the own buckets hold about T * m rows over the T tables this handle
+// probes, and the sample is 5 sqrt(T m), at least 128 and at most 2048, a multiple of 64.  Measured optima this rule
+// has to meet (batch time against sample size): one tree of 1M clustered 100-d rows (T m = 172): 128; 30 trees of
+// 768-d rows (3.4 k): 256; 30 trees of 100-d rows (5.9 k): 256-384; 30 trees of SIFT-shaped rows (58 k, buckets of up
+// to 31 k rows): 1024-2048, where 256 is 18 % slower.
+static int32_t seed_sample_for(const dpf_index *ix)
+{
+    double s1 = 0, s2 = 0;
+    for (uint32_t len : ix->h_leaf_len) { s1 += (double)len; s2 += (double)len * (double)len; }
+    if (s1 <= 0) return 256;
+    const int t_end = ix->cfg.table_end > 0 ? ix->cfg.table_end : ix->cfg.num_tables;
+    const int tables = std::max(1, t_end - ix->cfg.table_begin);
+    const double want = 5.0 * std::sqrt((double)tables * (s2 / s1));
+    const int64_t v = ((int64_t)want + 63) / 64 * 64;
+    return (int32_t)std::min<int64_t>(2048, std::max<int64_t>(128, v));
+}
+
 static int upload_snapshot(dpf_index *ix, ForestSnapshot &s)
 {
     int rc;
@@ -517,6 +538,7 @@ static int upload_snapshot(dpf_index *ix, ForestSnapshot &s)
     if ((rc = upload(ix, ix->d_leaf_tile0, leaf_tile0)) != DPF_OK) return rc;
     ix->h_leaf_len.resize(s.leaf_off.size() - 1);
     for (size_t l = 0; l + 1 < s.leaf_off.size(); l++) ix->h_leaf_len[l] = s.leaf_off[l + 1] - s.leaf_off[l];
+    ix->auto_seed_cap = seed_sample_for(ix);
     ix->ntiles = ix->nutiles;
     ix->num_leaves = (int64_t)s.leaf_off.size() - 1;
     if ((rc = upload(ix, ix->d_roots, s.roots)) != DPF_OK) return rc;
@@ -596,6 +618,7 @@ static int device_snapshot(dpf_index *ix, int64_t total)
     HIPCHECK(ix, hipMemcpy(off.data(), ix->d_leaf_off.p, off.size() * 4, hipMemcpyDeviceToHost));
     ix->h_leaf_len.resize((size_t)f.num_leaves);
     for (size_t l = 0; l < ix->h_leaf_len.size(); l++) ix->h_leaf_len[l] = off[l + 1] - off[l];
+    ix->auto_seed_cap = seed_sample_for(ix);
     ix->st.num_dnodes = f.num_dnodes;
     ix->st.num_leaves = f.num_leaves;
     ix->st.max_leaf = f.max_leaf;
@@ -1137,7 +1160,7 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
 {
     *done = false;
     const int32_t EMIT_CAP = emit_cap_setting(ix);
-    const int32_t SEED_CAP = ix->opt_seed_cap;            // seed sample per query
+    const int32_t SEED_CAP = ix->opt_seed_cap >= 0 ? ix->opt_seed_cap : ix->auto_seed_cap;   // seed sample per query
     const int L = ix->cfg.num_tables;
     const int64_t nl = ix->num_leaves;
     HIPCHECK(ix, ix->ws_hashes.ensure((size_t)nq * L * 4));
@@ -1711,7 +1734,8 @@ extern "C" int dpf_set_option(dpf_index *ix, int32_t option, int64_t value)
         ix->opt_early_permille = (int32_t)value;
         return DPF_OK;
     case DPF_OPT_SEED_SAMPLE:
-        if (value != 0 && (value < 16 || value > 4096)) return fail(ix, DPF_EINVAL, "dpf_set_option: seed sample must be 0 (none) or in [16, 4096]");
+        if (value != 0 && value != -1 && (value < 16 || value > 4096))
+            return fail(ix, DPF_EINVAL, "dpf_set_option: seed sample must be -1 (by bucket sizes), 0 (none) or in [16, 4096]");
         ix->opt_seed_cap = (int32_t)value;
         return DPF_OK;
     case DPF_OPT_SHORT_RERANK:
