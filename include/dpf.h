@@ -63,7 +63,12 @@ enum { DPF_FLAG_HASH_ONLY = 1,
  * integer-valued inside one window of 256 values within +-2048 (SIFT's 0..255) keeps an int8 copy of them beside the fp16 one, and a
  * batch whose queries fit the window too is scanned with exact integer products on half the bytes (same results;
  * other batches take the fp16 scan; the flag is for A/B). */
-       DPF_FLAG_NO_INT8 = 16 };
+       DPF_FLAG_NO_INT8 = 16,
+/* DPF_FLAG_NO_CENTRE: the fp16 copies of an l2 handle are taken of the rows as they are.  Without it they are taken
+ * around the mean of the resident rows (queries likewise): distances do not change, the rounding distances the filter
+ * has to allow for shrink with the values - rows with a large common offset stay on the bucket-major path instead of
+ * forwarding everything (same results; the flag is for A/B). */
+       DPF_FLAG_NO_CENTRE = 32 };
 
 /* The subset of the reference's Typesafe-Config keys the path consumes
  * (TestSettings.scala:8-45; read at LSH:19-33, Dense:39-58). */

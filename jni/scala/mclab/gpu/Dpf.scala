@@ -38,6 +38,7 @@ object Dpf {
   val FlagHostForest = 4
   val FlagFullFilter = 8
   val FlagNoInt8 = 16
+  val FlagNoCentre = 32
 
   /** The int32 fields of `dpf_config`, in declaration order (checked against include/dpf.h by tests/test_jni_shim.py). */
   val ConfigIntFields: Array[String] = Array(

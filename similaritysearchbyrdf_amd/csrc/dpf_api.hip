@@ -159,6 +159,8 @@ struct dpf_index {
     DevBuf d_base8, d_norm8, d_slot_nj8, d_i8_probe;   // rows minus the window's centre, their |x'|^2, -floor(|x'|^2 / 2) in bucket order
     DevBuf ws_q8, ws_qc8;                    // the query batch's int8 rows and scan records
     bool i8_ok = false;
+    DevBuf d_mu;                             // the centre the fp16 copies of an l2 handle are taken around ([dpad] floats)
+    bool centred = false;
     int ks8 = 0;                             // 64-byte steps per int8 row
     float i8_offset = 0.f;                   // the window's centre
     bool last_scan_int8 = false;
@@ -343,7 +345,7 @@ extern "C" void dpf_destroy(dpf_index *ix)
     for (int i = 0; i < 6; i++) if (ix->ev_scan[i]) (void)hipEventDestroy(ix->ev_scan[i]);
     DevBuf *more[] = {&ix->ws_emit_ucnt, &ix->ws_emit_v, &ix->ws_leaf_units, &ix->ws_unit_off, &ix->ws_q_leaves, &ix->ws_q_leaf_cnt, &ix->d_leaf_tile0, &ix->ws_units, &ix->d_tiles, &ix->ws_lq_off, &ix->ws_lq_cursor, &ix->ws_leaf_queries,
                       &ix->ws_seed_cand, &ix->ws_seed_cnt, &ix->ws_seed_ids, &ix->ws_seed_scores, &ix->ws_emit, &ix->ws_emit_cnt,
-                      &ix->d_base16, &ix->ws_q16, &ix->d_base16n, &ix->ws_q16n, &ix->d_base16e, &ix->ws_q16e, &ix->ws_flag, &ix->ws_tau, &ix->ws_qc, &ix->d_slot_norm, &ix->d_base16t, &ix->d_slot_tail, &ix->ws_q16t, &ix->ws_ovf, &ix->d_base8, &ix->d_norm8, &ix->d_slot_nj8, &ix->d_i8_probe, &ix->ws_q8, &ix->ws_qc8, &ix->sub_q, &ix->sub_qids, &ix->sub_ids,
+                      &ix->d_base16, &ix->ws_q16, &ix->d_base16n, &ix->ws_q16n, &ix->d_base16e, &ix->ws_q16e, &ix->ws_flag, &ix->ws_tau, &ix->ws_qc, &ix->d_slot_norm, &ix->d_base16t, &ix->d_slot_tail, &ix->ws_q16t, &ix->ws_ovf, &ix->d_base8, &ix->d_norm8, &ix->d_slot_nj8, &ix->d_i8_probe, &ix->ws_q8, &ix->ws_qc8, &ix->d_mu, &ix->sub_q, &ix->sub_qids, &ix->sub_ids,
                       &ix->sub_scores, &ix->sub_ws[0], &ix->sub_ws[1], &ix->sub_ws[2], &ix->sub_ws[3], &ix->sub_ws[4], &ix->sub_ws[5]};
     for (DevBuf *b : more) b->release();
     delete ix;
@@ -650,18 +652,10 @@ static int finish_fit(dpf_index *ix, int64_t total, int64_t new_rows)
     int rc;
     const int d = ix->cfg.dim;
     const size_t row_bytes = (size_t)ix->dpad * ix->elem;
-    if (ix->bucket_major && ix->ks16 > 0 && new_rows > 0) {
-        HIPCHECK(ix, ix->d_base16.ensure((size_t)new_rows * ix->ks16 * 32 * 2));
-        HIPCHECK(ix, ix->d_base16n.ensure((size_t)new_rows * 4));
-        HIPCHECK(ix, ix->d_base16e.ensure((size_t)new_rows * 4));
-        const bool tails = ix->filter_dim < d;
-        if (tails) HIPCHECK(ix, ix->d_base16t.ensure((size_t)new_rows * 16));
-        launch_rows_to_f16(ix->d_base.as<float>(), ix->dpad, std::min(d, ix->filter_dim), new_rows, ix->d_base16.as<uint16_t>(), ix->ks16 * 32,
-                            ix->d_base16n.as<float>(), ix->d_base16e.as<float>(), nullptr, nullptr, d, tails ? (uint4 *)ix->d_base16t.p : nullptr);
-    }
     // The int8 copy, when the resident rows allow it: every value an integer, all of them inside one window of 256
     // values (SIFT's 0..255, for one); the window's centre is subtracted, which leaves distances as they are.
     ix->i8_ok = false;
+    bool i8_window = false;
     if (ix->bucket_major && ix->ks16 > 0 && new_rows > 0 && ix->cfg.metric == DPF_METRIC_L2 && d <= 256 && !(ix->cfg.flags & DPF_FLAG_NO_INT8)) {
         const int32_t init[4] = {INT32_MAX, INT32_MIN, 0, 0};
         int32_t got[4];
@@ -674,15 +668,49 @@ static int finish_fit(dpf_index *ix, int64_t total, int64_t new_rows)
         // (within +-2048 every integer is an fp16 value too: the thresholds the two forms of the scan share - seed radii,
         // refinements - then carry no rounding allowance for such a batch)
         if (got[2] == 0 && std::isfinite(lo) && std::isfinite(hi) && hi - lo <= 255.0f && std::fabs(lo) <= 2048.0f && std::fabs(hi) <= 2048.0f) {
+            i8_window = true;
             ix->ks8 = (d + 63) / 64;
             ix->i8_offset = lo + 128.0f;
-            HIPCHECK(ix, ix->d_base8.ensure((size_t)new_rows * ix->ks8 * 64));
-            HIPCHECK(ix, ix->d_norm8.ensure((size_t)new_rows * 4));
-            launch_rows_to_i8(ix->d_base.as<float>(), ix->dpad, d, new_rows, ix->i8_offset, ix->d_base8.as<int8_t>(), ix->ks8 * 64,
-                              ix->d_norm8.as<int32_t>(), nullptr, nullptr, ix->d_i8_probe.as<int32_t>() + 3, nullptr);
-            HIPCHECK(ix, hipMemcpy(got, ix->d_i8_probe.p, 16, hipMemcpyDeviceToHost));
-            ix->i8_ok = got[3] == 0;
         }
+    }
+    // l2 handles take their fp16 copies around the mean row: distances do not change, and the rounding distances of
+    // the copies shrink with the values (rows of 1000 +- 1 would otherwise round to steps of 0.5).  Not where the
+    // int8 copy exists: its rows are exact in fp16 as they are.
+    ix->centred = false;
+    if (ix->bucket_major && ix->ks16 > 0 && new_rows > 0 && ix->cfg.metric == DPF_METRIC_L2 && !i8_window && !(ix->cfg.flags & DPF_FLAG_NO_CENTRE)) {
+        HIPCHECK(ix, ix->d_mu.ensure((size_t)ix->dpad * 4));
+        HIPCHECK(ix, hipMemset(ix->d_mu.p, 0, (size_t)ix->dpad * 4));
+        launch_col_sums(ix->d_base.as<float>(), ix->dpad, d, new_rows, ix->d_mu.as<float>(), nullptr);
+        std::vector<float> mu((size_t)ix->dpad, 0.f);
+        HIPCHECK(ix, hipMemcpy(mu.data(), ix->d_mu.p, (size_t)d * 4, hipMemcpyDeviceToHost));
+        bool any = false;
+        for (int c = 0; c < d; c++) {
+            float m = mu[c] / (float)new_rows;
+            if (!std::isfinite(m) || std::fabs(m) > 1.0e30f) m = 0.f;
+            mu[c] = m;
+            any = any || m != 0.f;
+        }
+        HIPCHECK(ix, hipMemcpy(ix->d_mu.p, mu.data(), (size_t)ix->dpad * 4, hipMemcpyHostToDevice));
+        ix->centred = any;
+    }
+    if (ix->bucket_major && ix->ks16 > 0 && new_rows > 0) {
+        HIPCHECK(ix, ix->d_base16.ensure((size_t)new_rows * ix->ks16 * 32 * 2));
+        HIPCHECK(ix, ix->d_base16n.ensure((size_t)new_rows * 4));
+        HIPCHECK(ix, ix->d_base16e.ensure((size_t)new_rows * 4));
+        const bool tails = ix->filter_dim < d;
+        if (tails) HIPCHECK(ix, ix->d_base16t.ensure((size_t)new_rows * 16));
+        launch_rows_to_f16(ix->d_base.as<float>(), ix->dpad, std::min(d, ix->filter_dim), new_rows, ix->d_base16.as<uint16_t>(), ix->ks16 * 32,
+                            ix->d_base16n.as<float>(), ix->d_base16e.as<float>(), nullptr, nullptr, d, tails ? (uint4 *)ix->d_base16t.p : nullptr,
+                            ix->centred ? ix->d_mu.as<float>() : nullptr);
+    }
+    if (i8_window) {
+        int32_t got[4];
+        HIPCHECK(ix, ix->d_base8.ensure((size_t)new_rows * ix->ks8 * 64));
+        HIPCHECK(ix, ix->d_norm8.ensure((size_t)new_rows * 4));
+        launch_rows_to_i8(ix->d_base.as<float>(), ix->dpad, d, new_rows, ix->i8_offset, ix->d_base8.as<int8_t>(), ix->ks8 * 64,
+                          ix->d_norm8.as<int32_t>(), nullptr, nullptr, ix->d_i8_probe.as<int32_t>() + 3, nullptr);
+        HIPCHECK(ix, hipMemcpy(got, ix->d_i8_probe.p, 16, hipMemcpyDeviceToHost));
+        ix->i8_ok = got[3] == 0;
     }
     HIPCHECK(ix, hipDeviceSynchronize());
     ix->base_rows = new_rows;
@@ -1278,7 +1306,7 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
         if (tails) HIPCHECK(ix, ix->ws_q16t.ensure((size_t)nq * 16));
         launch_rows_to_f16((const float *)qpad, ix->dpad, std::min(ix->cfg.dim, ix->filter_dim), nq, ix->ws_q16.as<uint16_t>(), ix->ks16 * 32,
                            ix->ws_q16n.as<float>(), ix->ws_q16e.as<float>(), stream, seeds_fp16 ? nullptr : &tp, ix->cfg.dim,
-                           tails ? (uint4 *)ix->ws_q16t.p : nullptr);
+                           tails ? (uint4 *)ix->ws_q16t.p : nullptr, ix->centred ? ix->d_mu.as<float>() : nullptr);
         if (seeds_fp16)
             launch_seed_radius(rp.cand, rp.cnt, SEED_CAP, ix->ws_q16.as<uint16_t>(), ix->d_base16.as<uint16_t>(), ix->ks16,
                                ix->ws_q16n.as<float>(), ix->ws_q16e.as<float>(), ix->d_base16e.as<float>(),

@@ -178,9 +178,11 @@ struct TauParams {
 };
 // dim_all > dim: the dimensions [dim, dim_all) (at most 8) go to tails[r] instead of the row; norms cover the row,
 // errs all dim_all dimensions
+// mu (optional, [dim_all] floats): subtracted from every row before the conversion
 void launch_rows_to_f16(const float *src, int64_t src_stride, int dim, int64_t n, uint16_t *dst, int dst_stride,
                          float *norms, float *errs, hipStream_t stream, const TauParams *tau = nullptr, int dim_all = 0,
-                         uint4 *tails = nullptr);
+                         uint4 *tails = nullptr, const float *mu = nullptr);
+void launch_col_sums(const float *src, int64_t src_stride, int dim, int64_t n, float *sums, hipStream_t stream);
 // int8 copies for the exact integer scan.  launch_i8_range: out[0] = smallest value (order-preserving int image of the
 // float), out[1] = largest, out[2] != 0 when a value is no integer (out[] preset to INT32_MAX, INT32_MIN, 0).
 // launch_rows_to_i8: dst rows of dst_stride bytes (a multiple of 64) = value - offset, zero padded; *bad is raised when a

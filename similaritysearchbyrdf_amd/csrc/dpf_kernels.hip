@@ -1920,19 +1920,30 @@ __device__ __forceinline__ uint16_t to_f16_measured(float x, float &sq, float &e
 }
 
 // the dimensions [dim, dim_all) of row r (at most 8) as one 16-byte tail, zero padded; their rounding distance joins err2
-__device__ __forceinline__ void tail_to_f16(const float *__restrict__ row, int dim, int dim_all, uint4 *__restrict__ out, float &err2)
+__device__ __forceinline__ void tail_to_f16(const float *__restrict__ row, int dim, int dim_all, uint4 *__restrict__ out, float &err2,
+                                            const float *__restrict__ mu, float &shifted2)
 {
     uint16_t o[8];
     float unused = 0.f;
 #pragma unroll
-    for (int e = 0; e < 8; e++) o[e] = dim + e < dim_all ? to_f16_measured(row[dim + e], unused, err2) : (uint16_t)0;
+    for (int e = 0; e < 8; e++) {
+        o[e] = 0;
+        if (dim + e < dim_all) {
+            const float x = mu ? row[dim + e] - mu[dim + e] : row[dim + e];
+            shifted2 = fmaf(x, x, shifted2);
+            o[e] = to_f16_measured(x, unused, err2);
+        }
+    }
     *out = make_uint4(o[0] | ((uint32_t)o[1] << 16), o[2] | ((uint32_t)o[3] << 16), o[4] | ((uint32_t)o[5] << 16), o[6] | ((uint32_t)o[7] << 16));
 }
 
+// mu (optional): a centre subtracted from every row before the conversion (l2 handles: distances do not change, the
+// rounding distances shrink with the values).  The subtraction is one fp32 operation per element; its own rounding, at
+// most 2^-24 of the shifted value, joins the measured distance as 1.2e-7 |shifted row|.
 template <bool TAU>
 __global__ void k_rows_to_f16(const float *__restrict__ src, int64_t src_stride, int dim, int64_t n,
                                uint16_t *__restrict__ dst, int dst_stride, float *__restrict__ norms, float *__restrict__ errs,
-                               TauParams tp, int dim_all, uint4 *__restrict__ tails)
+                               TauParams tp, int dim_all, uint4 *__restrict__ tails, const float *__restrict__ mu)
 {
     const int per_row = dst_stride >> 3;                  // lanes per row: a power of two up to 64
     const int64_t total = n * per_row;
@@ -1941,12 +1952,14 @@ __global__ void k_rows_to_f16(const float *__restrict__ src, int64_t src_stride,
     const int64_t r = live ? i / per_row : 0;
     const int c0 = (int)(i - r * per_row) * 8;
     uint16_t o[8];
-    float ss = 0.f, ee = 0.f;
+    float ss = 0.f, ee = 0.f, xx = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; e++) {
         o[e] = 0;
         if (live && c0 + e < dim) {
-            const float x = src[r * src_stride + c0 + e];
+            float x = src[r * src_stride + c0 + e];
+            if (mu) x -= mu[c0 + e];
+            xx = fmaf(x, x, xx);
             // nearest fp16, clamped to the finite range; what would be subnormal becomes 0 so that
             // the matrix cores see exactly the values the norms and distances are taken from
             _Float16 h = (_Float16)fminf(fmaxf(x, -65504.0f), 65504.0f);
@@ -1963,11 +1976,11 @@ __global__ void k_rows_to_f16(const float *__restrict__ src, int64_t src_stride,
         w.x = o[0] | ((uint32_t)o[1] << 16); w.y = o[2] | ((uint32_t)o[3] << 16);
         w.z = o[4] | ((uint32_t)o[5] << 16); w.w = o[6] | ((uint32_t)o[7] << 16);
         *(uint4 *)(dst + i * 8) = w;
-        if (tails && c0 == 0) tail_to_f16(src + r * src_stride, dim, dim_all, tails + r, ee);
+        if (tails && c0 == 0) tail_to_f16(src + r * src_stride, dim, dim_all, tails + r, ee, mu, xx);
     }
-    for (int m = 1; m < per_row; m <<= 1) { ss += __shfl_xor(ss, m); ee += __shfl_xor(ee, m); }   // rows never straddle a wave
+    for (int m = 1; m < per_row; m <<= 1) { ss += __shfl_xor(ss, m); ee += __shfl_xor(ee, m); xx += __shfl_xor(xx, m); }   // rows never straddle a wave
     if (live && c0 == 0) {
-        const float er = sqrtf(ee * 1.0001f) * 1.00001f;
+        const float er = sqrtf(ee * 1.0001f) * 1.00001f + (mu ? 1.2e-7f * sqrtf(xx) : 0.f);
         norms[r] = ss; errs[r] = er;
         if (TAU) write_tau(tp, r, ss, er, dst_stride);
     }
@@ -1977,20 +1990,23 @@ __global__ void k_rows_to_f16(const float *__restrict__ src, int64_t src_stride,
 template <bool TAU>
 __global__ __launch_bounds__(256) void k_rows_to_f16_long(const float *__restrict__ src, int64_t src_stride, int dim, int64_t n,
                                                           uint16_t *__restrict__ dst, int dst_stride, float *__restrict__ norms,
-                                                          float *__restrict__ errs, TauParams tp, int dim_all, uint4 *__restrict__ tails)
+                                                          float *__restrict__ errs, TauParams tp, int dim_all, uint4 *__restrict__ tails,
+                                                          const float *__restrict__ mu)
 {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= n) return;                                   // whole waves leave together
-    float ss = 0.f, ee = 0.f;
-    if (tails && lane == 0) tail_to_f16(src + r * src_stride, dim, dim_all, tails + r, ee);
+    float ss = 0.f, ee = 0.f, xx = 0.f;
+    if (tails && lane == 0) tail_to_f16(src + r * src_stride, dim, dim_all, tails + r, ee, mu, xx);
     for (int c0 = lane * 8; c0 < dst_stride; c0 += 512) {
         uint16_t o[8];
 #pragma unroll
         for (int e = 0; e < 8; e++) {
             o[e] = 0;
             if (c0 + e < dim) {
-                const float x = src[r * src_stride + c0 + e];
+                float x = src[r * src_stride + c0 + e];
+                if (mu) x -= mu[c0 + e];
+                xx = fmaf(x, x, xx);
                 _Float16 h = (_Float16)fminf(fmaxf(x, -65504.0f), 65504.0f);
                 if (fabsf((float)h) < 6.103515625e-5f) h = (_Float16)0.0f;
                 o[e] = __builtin_bit_cast(uint16_t, h);
@@ -2005,13 +2021,29 @@ __global__ __launch_bounds__(256) void k_rows_to_f16_long(const float *__restric
         w.z = o[4] | ((uint32_t)o[5] << 16); w.w = o[6] | ((uint32_t)o[7] << 16);
         *(uint4 *)(dst + r * dst_stride + c0) = w;
     }
-    for (int m = 1; m < 64; m <<= 1) { ss += __shfl_xor(ss, m); ee += __shfl_xor(ee, m); }
+    for (int m = 1; m < 64; m <<= 1) { ss += __shfl_xor(ss, m); ee += __shfl_xor(ee, m); xx += __shfl_xor(xx, m); }
     if (lane == 0) {
-        const float er = sqrtf(ee * 1.0001f) * 1.00001f;
+        const float er = sqrtf(ee * 1.0001f) * 1.00001f + (mu ? 1.2e-7f * sqrtf(xx) : 0.f);
         norms[r] = ss; errs[r] = er;
         if (TAU) write_tau(tp, r, ss, er, dst_stride);
     }
 }
+// column sums of the rows (the centre the fp16 copies of an l2 handle are taken around): a workgroup adds 256 rows,
+// thread c the columns c, c + 256, ..., then one atomic per column and workgroup
+__global__ __launch_bounds__(256) void k_col_sums(const float *__restrict__ src, int64_t src_stride, int dim, int64_t n, float *__restrict__ sums)
+{
+    const int64_t r0 = (int64_t)blockIdx.x * 256, r1 = r0 + 256 < n ? r0 + 256 : n;
+    for (int c = threadIdx.x; c < dim; c += 256) {
+        float a = 0.f;
+        for (int64_t r = r0; r < r1; r++) a += src[r * src_stride + c];
+        atomicAdd(&sums[c], a);
+    }
+}
+void launch_col_sums(const float *src, int64_t src_stride, int dim, int64_t n, float *sums, hipStream_t stream)
+{
+    if (n > 0) hipLaunchKernelGGL(k_col_sums, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, src, src_stride, dim, n, sums);
+}
+
 // ---------------------------------------------------------------------------
 // k_seed_radius: first thresholds of an l2 batch from the fp16 copies
 // ---------------------------------------------------------------------------
@@ -2173,7 +2205,7 @@ void launch_seed_radius(const int32_t *cand, const int32_t *cnt, int64_t cand_st
 }
 
 void launch_rows_to_f16(const float *src, int64_t src_stride, int dim, int64_t n, uint16_t *dst, int dst_stride,
-                         float *norms, float *errs, hipStream_t stream, const TauParams *tau, int dim_all, uint4 *tails)
+                         float *norms, float *errs, hipStream_t stream, const TauParams *tau, int dim_all, uint4 *tails, const float *mu)
 {
     if (n <= 0) return;
     if (!tails || dim_all <= dim) { tails = nullptr; dim_all = dim; }
@@ -2181,14 +2213,14 @@ void launch_rows_to_f16(const float *src, int64_t src_stride, int dim, int64_t n
     const TauParams tp = tau ? *tau : TauParams();
     if (per_row > 64 || (per_row & (per_row - 1)) != 0) {
         const dim3 grid((unsigned)((n + 3) / 4)), block(256);
-        if (tau) hipLaunchKernelGGL((k_rows_to_f16_long<true>), grid, block, 0, stream, src, src_stride, dim, n, dst, dst_stride, norms, errs, tp, dim_all, tails);
-        else hipLaunchKernelGGL((k_rows_to_f16_long<false>), grid, block, 0, stream, src, src_stride, dim, n, dst, dst_stride, norms, errs, tp, dim_all, tails);
+        if (tau) hipLaunchKernelGGL((k_rows_to_f16_long<true>), grid, block, 0, stream, src, src_stride, dim, n, dst, dst_stride, norms, errs, tp, dim_all, tails, mu);
+        else hipLaunchKernelGGL((k_rows_to_f16_long<false>), grid, block, 0, stream, src, src_stride, dim, n, dst, dst_stride, norms, errs, tp, dim_all, tails, mu);
         return;
     }
     const int64_t total = n * (dst_stride / 8);
     const dim3 grid((unsigned)((total + 255) / 256)), block(256);
-    if (tau) hipLaunchKernelGGL((k_rows_to_f16<true>), grid, block, 0, stream, src, src_stride, dim, n, dst, dst_stride, norms, errs, tp, dim_all, tails);
-    else hipLaunchKernelGGL((k_rows_to_f16<false>), grid, block, 0, stream, src, src_stride, dim, n, dst, dst_stride, norms, errs, tp, dim_all, tails);
+    if (tau) hipLaunchKernelGGL((k_rows_to_f16<true>), grid, block, 0, stream, src, src_stride, dim, n, dst, dst_stride, norms, errs, tp, dim_all, tails, mu);
+    else hipLaunchKernelGGL((k_rows_to_f16<false>), grid, block, 0, stream, src, src_stride, dim, n, dst, dst_stride, norms, errs, tp, dim_all, tails, mu);
 }
 
 // ---------------------------------------------------------------------------

@@ -1207,3 +1207,41 @@ def test_int8_scan_on_row_table_and_subindex_shards():
             assert np.array_equal(fi, si) and np.array_equal(fs, ss, equal_nan=True), kw
         fast.close()
         slow.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim,offset", [(100, 300.0), (128, -1000.0), (40, 5.0e4), (768, 100.0)])
+def test_fp16_copies_are_taken_around_the_mean_row(dim, offset):
+    # l2 handles convert rows and queries to fp16 around the mean of the resident rows: the same answers as with
+    # DPF_FLAG_NO_CENTRE and as the gather path, and on rows with a large common offset far fewer rows forwarded
+    # (uncentred, 300 +- 1 rounds to steps of 0.25 and the filter has to allow for it)
+    n, nq = (6000, 80) if dim <= 128 else (2500, 40)
+    params, X, Q, pick = make_problem(n=n, nq=nq, dim=dim, bucket_overflow=50, table_num=2, permutation_num=2, n_clusters=6)
+    X = np.ascontiguousarray(X + np.float32(offset), dtype=np.float32)
+    Q = np.ascontiguousarray(Q + np.float32(offset), dtype=np.float32)
+    X[7] = X[3]                                                     # equal rows: ties by id
+    centred = DpfIndex(params, metric="l2")
+    plain = DpfIndex(dict(params, flags=32), metric="l2")           # DPF_FLAG_NO_CENTRE
+    slow = DpfIndex(dict(params, flags=2), metric="l2")             # DPF_FLAG_GATHER_ONLY
+    for ix in (centred, plain, slow):
+        ix.fit(X)
+    fwd = {}
+    for steps, k in ((1, 10), (0, 3)):
+        si, ss = slow.query_topk(pick, Q, steps=steps, k=k)
+        for name, ix in (("centred", centred), ("plain", plain)):
+            ii, is_ = ix.query_topk(pick, Q, steps=steps, k=k)
+            assert np.array_equal(ii, si) and np.array_equal(is_, ss, equal_nan=True), name
+            st = ix.stats()
+            fwd[name] = st["last_forwarded"] if st["last_path"] == 1 else 10 ** 9      # (the whole batch went the gather way)
+        assert centred.stats()["last_path"] == 1
+        assert fwd["centred"] <= fwd["plain"]
+    if abs(offset) >= 300.0 and dim <= 128:
+        assert 3 * fwd["centred"] < fwd["plain"], fwd
+    # a second fit moves the mean: the copies are taken again around the new one
+    centred.fit(X[:500] + np.float32(7.0))
+    slow.fit(X[:500] + np.float32(7.0))
+    ii, is_ = centred.query_topk(pick, Q, steps=1, k=10)
+    si, ss = slow.query_topk(pick, Q, steps=1, k=10)
+    assert np.array_equal(ii, si) and np.array_equal(is_, ss, equal_nan=True)
+    for ix in (centred, plain, slow):
+        ix.close()
