@@ -1282,6 +1282,9 @@ __device__ __forceinline__ float tail_dot(const uint4 &a, const uint4 &b)
 #ifndef LS16_COAL
 #define LS16_COAL 0
 #endif
+#ifndef LS16_SLICE_AHEAD
+#define LS16_SLICE_AHEAD 0
+#endif
 __device__ __forceinline__ f16x8 operand_from_quads(const f16x8 &v, int src4)
 {
     const i32x4 w = __builtin_bit_cast(i32x4, v);
@@ -1423,6 +1426,26 @@ __device__ __forceinline__ void leafscan_chunks(const LeafScanParams &p, const u
         } else {
 #pragma unroll
             for (int rb = 0; rb < RB; rb++) acc[rb] = (f32x4){nJ[rb], nJ[rb], nJ[rb], nJ[rb]};
+#if LS16_SLICE_AHEAD
+            // the next slice of the query rows is requested before this slice's products (one wave per SIMD: nothing
+            // else hides the round trip of a slice)
+            f16x8 qn[QS];
+#pragma unroll
+            for (int s0 = 0; s0 < KS; s0 += QS) {
+                if (s0 + QS < KS) {
+#pragma unroll
+                    for (int t = 0; t < QS; t++) qn[t] = *(const f16x8 *)(qrow + 32 * (s0 + QS + t));
+                }
+#pragma unroll
+                for (int rb = 0; rb < RB; rb++) {
+                    if (rb * 16u >= rows && rb > 0) continue;
+#pragma unroll
+                    for (int t = 0; t < QS; t++) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qa[t], xb[rb][s0 + t], acc[rb], 0, 0, 0);
+                }
+#pragma unroll
+                for (int t = 0; t < QS; t++) qa[t] = qn[t];
+            }
+#else
 #pragma unroll
             for (int s0 = 0; s0 < KS; s0 += QS) {
                 if (s0 > 0) {
@@ -1436,6 +1459,7 @@ __device__ __forceinline__ void leafscan_chunks(const LeafScanParams &p, const u
                     for (int t = 0; t < QS; t++) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qa[t], xb[rb][s0 + t], acc[rb], 0, 0, 0);
                 }
             }
+#endif
         }
         // lane l holds d = q~(MFMA row 4g + r) . x~(rb*16 + i16) - J in acc[rb][r]
         if (DPF_ABLATION(p, 1)) {                            // ablation runs: loads and products only
