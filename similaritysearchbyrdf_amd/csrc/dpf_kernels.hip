@@ -1470,13 +1470,12 @@ __device__ __forceinline__ void leafscan_chunks(const LeafScanParams &p, const u
             continue;
         }
         // the common case first: nothing of this lane's 16 scores reaches its query's threshold
+        const float4 Gs = *(const float4 *)(s_G + 4 * g);     // the thresholds of this lane's four query slots
         if constexpr (I8) {
-            const float4 Gs = *(const float4 *)(s_G + 4 * g);
             const int any = (int)(best_of<RB>(acc, 0) >= __float_as_int(Gs.x)) | (int)(best_of<RB>(acc, 1) >= __float_as_int(Gs.y)) |
                             (int)(best_of<RB>(acc, 2) >= __float_as_int(Gs.z)) | (int)(best_of<RB>(acc, 3) >= __float_as_int(Gs.w));
             if (__ballot(any != 0) == 0) continue;
         } else {
-            const float4 Gs = *(const float4 *)(s_G + 4 * g);
             const float e0 = best_of<RB>(acc, 0) - Gs.x;
             const float e1 = best_of<RB>(acc, 1) - Gs.y;
             const float e2 = best_of<RB>(acc, 2) - Gs.z;
@@ -1486,8 +1485,9 @@ __device__ __forceinline__ void leafscan_chunks(const LeafScanParams &p, const u
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int slot = 4 * g + r;
+            const float Gf = r == 0 ? Gs.x : r == 1 ? Gs.y : r == 2 ? Gs.z : Gs.w;
             val Gr;
-            if constexpr (I8) Gr = __float_as_int(s_G[slot]); else Gr = s_G[slot];
+            if constexpr (I8) Gr = __float_as_int(Gf); else Gr = Gf;
             if (__ballot(best_of<RB>(acc, r) >= Gr) == 0) continue;
             const float4 sc = s_slot[slot];           // {G2, query index, |q - q~| or slack, |q~|^2}
             const int32_t qq = __float_as_int(sc.y), qidq = s_qid[slot];
