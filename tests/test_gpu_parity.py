@@ -802,7 +802,7 @@ def test_overflowed_queries_take_the_gather_path_alone(metric, with_qids):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(48))
 def test_random_configurations(seed):
     # a seeded draw over the configuration space: hash family, index transform, trie geometry, overflow
     # threshold, dimension, metric, k, search steps; scan path == gather path (bit for bit) == oracle
@@ -821,6 +821,18 @@ def test_random_configurations(seed):
     params, X, Q, pick = make_problem(n=n, nq=nq, dim=dim, family=family, type_of_index=toi, partition_bits=pb,
                                       dir_node_size=dns, bucket_bits=bb, bucket_overflow=B, n_clusters=int(rng.randint(2, 40)),
                                       seed=50 + seed, **kw)
+    # (seeds from 24 on) the values themselves: as drawn; integers inside one window of 256 values (the int8 scan, where
+    # the metric is l2 and the rows are short enough); floats with a common offset (fp16 copies around the mean row)
+    kind = ["plain", "integers", "offset"][seed % 3] if seed >= 24 else "plain"
+    if kind == "integers":
+        lo = float([0, -128, 40, -700][rng.randint(4)])
+        scale = 255.0 / max(float(X.max() - X.min()), 1e-6)
+        X = np.clip(np.rint((X - X.min()) * scale * 0.9 + lo + 10.0), lo, lo + 255.0).astype(np.float32)
+        Q = np.clip(np.rint(X[pick] + rng.randint(-3, 4, size=Q.shape)), lo, lo + 255.0).astype(np.float32)
+    elif kind == "offset":
+        shift = np.float32([30.0, -250.0, 2000.0][rng.randint(3)])
+        X = np.ascontiguousarray(X + shift, dtype=np.float32)
+        Q = np.ascontiguousarray(Q + shift, dtype=np.float32)
     fast = DpfIndex(params, metric=metric, top_k=k)
     slow = DpfIndex(dict(params, flags=2), metric=metric, top_k=k)
     fast.fit(X)
@@ -830,7 +842,10 @@ def test_random_configurations(seed):
     Q64 = Q.astype(np.float64)
     steps = int(rng.randint(0, pb + 1))
     fi, fs = fast.query_topk(pick, Q, steps=steps, k=k)
-    assert fast.stats()["last_path"] == 1
+    if kind == "plain":
+        assert fast.stats()["last_path"] == 1
+    if kind == "integers" and metric == "l2" and fast.stats()["last_path"] == 1:
+        assert fast.stats()["last_scan_int8"] == 1
     si, ss = slow.query_topk(pick, Q, steps=steps, k=k)
     assert np.array_equal(fi, si) and np.array_equal(fs, ss, equal_nan=True)
     off, ids = orc.query_batch(pick, Q64, steps=steps)
