@@ -312,8 +312,10 @@ enum {
     DPF_OPT_SCAN_PASSES = 8,         /* slices the scan's work units are run in, thresholds refined in between: 2, 3, or
                                         0 = 3 for rows of 16 steps of 32 dimensions and more, 2 otherwise */
     DPF_OPT_EARLY_PASS_PERMILLE = 9, /* with 3 passes: share of the units in the first of them (40) */
-    DPF_OPT_EXACT_SEEDS = 10         /* 1: l2 handles score the seed sample exactly from the fp32 rows, as dot handles do
+    DPF_OPT_EXACT_SEEDS = 10,        /* 1: l2 handles score the seed sample exactly from the fp32 rows, as dot handles do
                                         (default 0: an upper bound of the k-th best distance from the fp16 copies) */
+    DPF_OPT_KEEP_FORWARDED = 11      /* 1: every row the scan forwarded is scored exactly (default 0: rows forwarded under a
+                                        threshold the query has tightened past since are dropped before the exact rerank) */
 };
 int dpf_set_option(dpf_index *ix, int32_t option, int64_t value);
 

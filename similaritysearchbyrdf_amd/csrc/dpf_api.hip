@@ -159,6 +159,8 @@ struct dpf_index {
     DevBuf d_base8, d_norm8, d_slot_nj8, d_i8_probe;   // rows minus the window's centre, their |x'|^2, -floor(|x'|^2 / 2) in bucket order
     DevBuf ws_q8, ws_qc8;                    // the query batch's int8 rows and scan records
     bool i8_ok = false;
+    DevBuf d_bounds;                         // k_tile_maxnorm's maxima over the tiles
+    float tile_bounds[3] = {0.f, 0.f, 0.f};  // the largest |x~| bound and rounding-distance bound of a tile, the largest squared tail norm
     DevBuf d_mu;                             // the centre the fp16 copies of an l2 handle are taken around ([dpad] floats)
     bool centred = false;
     int ks8 = 0;                             // 64-byte steps per int8 row
@@ -201,7 +203,7 @@ struct dpf_index {
     int32_t opt_emit_cap = 0, opt_bucket_list_cap = 0, opt_first_permille = 100, opt_seed_cap = -1;   // seed sample: -1 = by the forest's bucket sizes
     int32_t auto_seed_cap = 256;             // what -1 stands for, set when the forest is built (seed_sample_for)
     int32_t opt_scan_passes = 0, opt_early_permille = 40;   // passes: 0 = by row length (3 from 16 steps on), 2 or 3
-    bool opt_sync_sizes = false, opt_short_rerank = true, opt_exact_seeds = false;
+    bool opt_sync_sizes = false, opt_short_rerank = true, opt_exact_seeds = false, opt_keep_forwarded = false;
     int64_t opt_projection_min_rows = 4096;           // batches of at least this many vectors hash on the matrix cores (0: never)
 };
 
@@ -345,7 +347,7 @@ extern "C" void dpf_destroy(dpf_index *ix)
     for (int i = 0; i < 6; i++) if (ix->ev_scan[i]) (void)hipEventDestroy(ix->ev_scan[i]);
     DevBuf *more[] = {&ix->ws_emit_ucnt, &ix->ws_emit_v, &ix->ws_leaf_units, &ix->ws_unit_off, &ix->ws_q_leaves, &ix->ws_q_leaf_cnt, &ix->d_leaf_tile0, &ix->ws_units, &ix->d_tiles, &ix->ws_lq_off, &ix->ws_lq_cursor, &ix->ws_leaf_queries,
                       &ix->ws_seed_cand, &ix->ws_seed_cnt, &ix->ws_seed_ids, &ix->ws_seed_scores, &ix->ws_emit, &ix->ws_emit_cnt,
-                      &ix->d_base16, &ix->ws_q16, &ix->d_base16n, &ix->ws_q16n, &ix->d_base16e, &ix->ws_q16e, &ix->ws_flag, &ix->ws_tau, &ix->ws_qc, &ix->d_slot_norm, &ix->d_base16t, &ix->d_slot_tail, &ix->ws_q16t, &ix->ws_ovf, &ix->d_base8, &ix->d_norm8, &ix->d_slot_nj8, &ix->d_i8_probe, &ix->ws_q8, &ix->ws_qc8, &ix->d_mu, &ix->sub_q, &ix->sub_qids, &ix->sub_ids,
+                      &ix->d_base16, &ix->ws_q16, &ix->d_base16n, &ix->ws_q16n, &ix->d_base16e, &ix->ws_q16e, &ix->ws_flag, &ix->ws_tau, &ix->ws_qc, &ix->d_slot_norm, &ix->d_base16t, &ix->d_slot_tail, &ix->ws_q16t, &ix->ws_ovf, &ix->d_base8, &ix->d_norm8, &ix->d_slot_nj8, &ix->d_i8_probe, &ix->ws_q8, &ix->ws_qc8, &ix->d_mu, &ix->d_bounds, &ix->sub_q, &ix->sub_qids, &ix->sub_ids,
                       &ix->sub_scores, &ix->sub_ws[0], &ix->sub_ws[1], &ix->sub_ws[2], &ix->sub_ws[3], &ix->sub_ws[4], &ix->sub_ws[5]};
     for (DevBuf *b : more) b->release();
     delete ix;
@@ -557,9 +559,13 @@ static int upload_snapshot(dpf_index *ix, ForestSnapshot &s)
         HIPCHECK(ix, ix->d_slot_norm.ensure(std::max<size_t>(ix->d_ids.cap, 16)));
         const bool tails = ix->filter_dim < ix->cfg.dim;
         if (tails) HIPCHECK(ix, ix->d_slot_tail.ensure(std::max<size_t>(ix->d_ids.cap, 16) * 4));
+        HIPCHECK(ix, ix->d_bounds.ensure(16));
+        HIPCHECK(ix, hipMemset(ix->d_bounds.p, 0, 16));
         launch_tile_maxnorm((uint4 *)ix->d_tiles.p, ix->nutiles, ix->d_ids.as<int32_t>(), ix->d_base16n.as<float>(), ix->d_base16e.as<float>(),
                             ix->row_begin, ix->row_begin + ix->base_rows, ix->d_slot_norm.as<float>(), nullptr,
-                            tails ? (const uint4 *)ix->d_base16t.p : nullptr, tails ? (uint4 *)ix->d_slot_tail.p : nullptr);
+                            tails ? (const uint4 *)ix->d_base16t.p : nullptr, tails ? (uint4 *)ix->d_slot_tail.p : nullptr,
+                            ix->d_bounds.as<uint32_t>());
+        HIPCHECK(ix, hipMemcpy(ix->tile_bounds, ix->d_bounds.p, 12, hipMemcpyDeviceToHost));
         if (ix->i8_ok) {
             HIPCHECK(ix, ix->d_slot_nj8.ensure(std::max<size_t>(s.ids.size() * 4, 16)));
             launch_slot_nj8(ix->d_ids.as<int32_t>(), (int64_t)s.ids.size(), ix->d_norm8.as<int32_t>(), ix->row_begin,
@@ -632,9 +638,13 @@ static int device_snapshot(dpf_index *ix, int64_t total)
         HIPCHECK(ix, ix->d_slot_norm.ensure(std::max<size_t>(ix->d_ids.cap, 16)));
         const bool tails = ix->filter_dim < ix->cfg.dim;
         if (tails) HIPCHECK(ix, ix->d_slot_tail.ensure(std::max<size_t>(ix->d_ids.cap, 16) * 4));
+        HIPCHECK(ix, ix->d_bounds.ensure(16));
+        HIPCHECK(ix, hipMemset(ix->d_bounds.p, 0, 16));
         launch_tile_maxnorm((uint4 *)ix->d_tiles.p, ix->nutiles, ix->d_ids.as<int32_t>(), ix->d_base16n.as<float>(), ix->d_base16e.as<float>(),
                             ix->row_begin, ix->row_begin + ix->base_rows, ix->d_slot_norm.as<float>(), nullptr,
-                            tails ? (const uint4 *)ix->d_base16t.p : nullptr, tails ? (uint4 *)ix->d_slot_tail.p : nullptr);
+                            tails ? (const uint4 *)ix->d_base16t.p : nullptr, tails ? (uint4 *)ix->d_slot_tail.p : nullptr,
+                            ix->d_bounds.as<uint32_t>());
+        HIPCHECK(ix, hipMemcpy(ix->tile_bounds, ix->d_bounds.p, 12, hipMemcpyDeviceToHost));
         if (ix->i8_ok) {
             HIPCHECK(ix, ix->d_slot_nj8.ensure(std::max<size_t>((size_t)num_ids * 4, 16)));
             launch_slot_nj8(ix->d_ids.as<int32_t>(), num_ids, ix->d_norm8.as<int32_t>(), ix->row_begin,
@@ -1415,8 +1425,19 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     const bool dedupe = unique_lists_lds(std::min(longest, EMIT_CAP)) <= 128 * 1024;   // the table of the longest list fits LDS
     if (dedupe) {
         HIPCHECK(ix, ix->ws_emit_ucnt.ensure((size_t)nq * 4));
+        // (entries forwarded under a threshold the query has tightened past since are left out as well)
+        PruneParams pr;
+        if (!ix->opt_keep_forwarded) {
+            pr.emit_v = ix->ws_emit_v.as<float>(); pr.tau = ix->ws_tau.as<int32_t>();
+            pr.qc = (const float4 *)ix->ws_qc.p; pr.qc8 = i8 ? (const float4 *)ix->ws_qc8.p : nullptr;
+            pr.q_tail = ix->filter_dim < ix->cfg.dim ? (const uint4 *)ix->ws_q16t.p : nullptr;
+            pr.gate = i8 ? i8_gate : nullptr;
+            pr.metric = ix->cfg.metric;
+            pr.c32 = leafscan_c32_of(ix->ks16 * 32);
+            pr.xr_max = ix->tile_bounds[0]; pr.cx_max = ix->tile_bounds[1]; pr.xt_max = ix->tile_bounds[2];
+        }
         launch_unique_lists(ix->ws_emit.as<int32_t>(), emit_cnt_of(ix), EMIT_CAP, longest, ix->ws_emit_ucnt.as<int32_t>(), nq,
-                            stream);
+                            stream, &pr);
     }
     fill_rerank_params(ix, rp, qpad, k, nullptr, dedupe ? ix->ws_emit_ucnt.as<int32_t>() : emit_cnt_of(ix),
                        ix->ws_emit.as<int32_t>(), d_ids, d_scores);
@@ -1768,6 +1789,9 @@ extern "C" int dpf_set_option(dpf_index *ix, int32_t option, int64_t value)
         return DPF_OK;
     case DPF_OPT_SHORT_RERANK:
         ix->opt_short_rerank = value != 0;
+        return DPF_OK;
+    case DPF_OPT_KEEP_FORWARDED:
+        ix->opt_keep_forwarded = value != 0;
         return DPF_OK;
     case DPF_OPT_EXACT_SEEDS:
         ix->opt_exact_seeds = value != 0;

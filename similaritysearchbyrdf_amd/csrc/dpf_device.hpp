@@ -159,7 +159,8 @@ void launch_bucket_scans(const uint32_t *lq_cnt, const uint32_t *leaf_tile0, int
 void launch_units(const uint32_t *lq_cnt, const int64_t *lq_off, const uint32_t *leaf_tile0, const uint4 *tiles, int64_t ntiles,
                   const int64_t *unit_off, uint4 *units, const int32_t *abort, hipStream_t stream);
 void launch_tile_maxnorm(uint4 *tiles, int64_t ntiles, const int32_t *ids, const float *norms, const float *errs, int64_t row_begin,
-                         int64_t row_end, float *slot_norms, hipStream_t stream, const uint4 *tails = nullptr, uint4 *slot_tails = nullptr);
+                         int64_t row_end, float *slot_norms, hipStream_t stream, const uint4 *tails = nullptr, uint4 *slot_tails = nullptr,
+                         uint32_t *bounds = nullptr);
 int leafscan_f16_steps(int dim);
 int leafscan_f16_filter_dim(int dim, int metric);
 int leafscan_tile_rows(int ks);
@@ -198,8 +199,20 @@ void launch_seed_radius(const int32_t *cand, const int32_t *cnt, int64_t cand_st
                         const float *q_norm, const float *q_err, const float *b_err, const uint4 *q_tail, const uint4 *b_tail,
                         int64_t row_begin, int64_t row_end, const TauParams &tau, int64_t nq, hipStream_t stream);
 size_t unique_lists_lds(int32_t longest);
+// what k_unique_lists needs to drop the entries of a forward list that the query's final threshold has passed by
+struct PruneParams {
+    const float *emit_v = nullptr;   // [nq][cap] the scan's bound per entry; nullptr: no pruning
+    const int32_t *tau = nullptr;    // [nq] final thresholds
+    const float4 *qc = nullptr;      // [nq] scan records (l2: A, dot: bound of |q~|; |q - q~|; |q~|^2; id) of the fp16 form ...
+    const float4 *qc8 = nullptr;     // ... and of the int8 form (or nullptr)
+    const uint4 *q_tail = nullptr;   // [nq] query tails of cut rows or nullptr
+    const int32_t *gate = nullptr;   // != nullptr and *gate == 0: the int8 form of the scan ran
+    int metric = 1;
+    float c32 = 0.f, xr_max = 0.f, cx_max = 0.f, xt_max = 0.f;
+};
 void launch_unique_lists(int32_t *emit, const int32_t *emit_cnt, int32_t cap, int32_t longest, int32_t *unique_cnt, int64_t nq,
-                         hipStream_t stream);
+                         hipStream_t stream, const PruneParams *prune = nullptr);
+float leafscan_c32_of(int stride);   // the scan's rounding allowance per unit of |q~|^2 + |x~|^2 for rows of `stride` fp16 elements
 // flag[0] = overflowed lists (their queries in list[]), flag[2] = longest list; then the 40 bytes at `flag` (flags,
 // the two scan totals and the int8 gate word) are copied to host_record (pinned host memory)
 void launch_overflow_list(const int32_t *emit_cnt, int64_t nq, int32_t cap, int32_t *flag, int32_t *list, int32_t *host_record,

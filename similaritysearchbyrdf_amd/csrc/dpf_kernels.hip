@@ -1189,32 +1189,61 @@ __device__ inline uint32_t ceil16_bits(float f)
     return u & 0xffff0000u;
 }
 
+// 16-byte tails (8 fp16 values, see leafscan_f16_filter_dim): inner product in fp32 (exact products)
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float tail_dot(const uint4 &a, const uint4 &b)
+{
+    float c = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, a.x), __builtin_bit_cast(f16x2, b.x), 0.f, false);
+    c = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, a.y), __builtin_bit_cast(f16x2, b.y), c, false);
+    c = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, a.z), __builtin_bit_cast(f16x2, b.z), c, false);
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, a.w), __builtin_bit_cast(f16x2, b.w), c, false);
+}
+
 // tiles[t].w = two upper bounds over the tile's resident rows, both rounded up to 8 significant bits:
 // the largest norm of the fp16 copies (upper half) and the largest rounding distance (lower half).
 // slot_norms[] = the squared norms again, in bucket order beside ids[]: the scan reads a tile's 64
 // norms as one 256-byte run instead of 64 scattered 4-byte reads that each pull a whole line.
+// bounds[0..2] (optional; non-negative floats, raised with integer atomicMax on their bit patterns): the largest of the
+// tiles' two bounds and the largest squared norm of a row's tail - what a reader of the forward lists that does not
+// know an entry's tile may assume of it.
 __global__ __launch_bounds__(256) void k_tile_maxnorm(uint4 *__restrict__ tiles, int64_t ntiles, const int32_t *__restrict__ ids,
                                                       const float *__restrict__ norms, const float *__restrict__ errs,
                                                       int64_t row_begin, int64_t row_end, float *__restrict__ slot_norms,
-                                                      const uint4 *__restrict__ tails, uint4 *__restrict__ slot_tails)
+                                                      const uint4 *__restrict__ tails, uint4 *__restrict__ slot_tails,
+                                                      uint32_t *__restrict__ bounds)
 {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= ntiles) return;
-    uint4 td = tiles[t];
-    float m = 0.f, e = 0.f;
-    for (uint32_t i = 0; i < td.z; i++) {
-        const int64_t id = ids[td.y + i];
-        float nn = 0.f;
-        uint4 tl = make_uint4(0u, 0u, 0u, 0u);
-        if (id >= row_begin && id < row_end) {
-            nn = norms[id - row_begin]; m = fmaxf(m, nn); e = fmaxf(e, errs[id - row_begin]);
-            if (tails) tl = tails[id - row_begin];
+    float xr = 0.f, cx = 0.f, tm = 0.f;
+    if (t < ntiles) {
+        uint4 td = tiles[t];
+        float m = 0.f, e = 0.f;
+        for (uint32_t i = 0; i < td.z; i++) {
+            const int64_t id = ids[td.y + i];
+            float nn = 0.f;
+            uint4 tl = make_uint4(0u, 0u, 0u, 0u);
+            if (id >= row_begin && id < row_end) {
+                nn = norms[id - row_begin]; m = fmaxf(m, nn); e = fmaxf(e, errs[id - row_begin]);
+                if (tails) { tl = tails[id - row_begin]; tm = fmaxf(tm, tail_dot(tl, tl)); }
+            }
+            slot_norms[td.y + i] = nn;
+            if (slot_tails) slot_tails[td.y + i] = tl;
         }
-        slot_norms[td.y + i] = nn;
-        if (slot_tails) slot_tails[td.y + i] = tl;
+        td.w = ceil16_bits(sqrtf(m) * 1.00001f) | (ceil16_bits(e) >> 16);
+        tiles[t] = td;
+        xr = __uint_as_float(td.w & 0xffff0000u);
+        cx = __uint_as_float(td.w << 16);
     }
-    td.w = ceil16_bits(sqrtf(m) * 1.00001f) | (ceil16_bits(e) >> 16);
-    tiles[t] = td;
+    if (bounds) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            xr = fmaxf(xr, __shfl_xor(xr, o)); cx = fmaxf(cx, __shfl_xor(cx, o)); tm = fmaxf(tm, __shfl_xor(tm, o));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicMax(bounds, __float_as_uint(xr));
+            atomicMax(bounds + 1, __float_as_uint(cx));
+            atomicMax(bounds + 2, __float_as_uint(tm));
+        }
+    }
 }
 
 void launch_units(const uint32_t *lq_cnt, const int64_t *lq_off, const uint32_t *leaf_tile0, const uint4 *tiles, int64_t ntiles,
@@ -1223,9 +1252,9 @@ void launch_units(const uint32_t *lq_cnt, const int64_t *lq_off, const uint32_t 
     if (ntiles > 0) hipLaunchKernelGGL(k_units, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, stream, lq_cnt, lq_off, leaf_tile0, tiles, ntiles, unit_off, units, abort);
 }
 void launch_tile_maxnorm(uint4 *tiles, int64_t ntiles, const int32_t *ids, const float *norms, const float *errs, int64_t row_begin,
-                         int64_t row_end, float *slot_norms, hipStream_t stream, const uint4 *tails, uint4 *slot_tails)
+                         int64_t row_end, float *slot_norms, hipStream_t stream, const uint4 *tails, uint4 *slot_tails, uint32_t *bounds)
 {
-    if (ntiles > 0) hipLaunchKernelGGL(k_tile_maxnorm, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, stream, tiles, ntiles, ids, norms, errs, row_begin, row_end, slot_norms, tails, slot_tails);
+    if (ntiles > 0) hipLaunchKernelGGL(k_tile_maxnorm, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, stream, tiles, ntiles, ids, norms, errs, row_begin, row_end, slot_norms, tails, slot_tails, bounds);
 }
 
 // Ablation switches of the scan (timing experiments that give wrong answers on purpose) exist only in
@@ -1261,15 +1290,6 @@ __device__ __forceinline__ int32_t best_of(const i32x4 (&acc)[RB], int r)
     return m;
 }
 
-// 16-byte tails (8 fp16 values, see leafscan_f16_filter_dim): inner product in fp32 (exact products)
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float tail_dot(const uint4 &a, const uint4 &b)
-{
-    float c = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, a.x), __builtin_bit_cast(f16x2, b.x), 0.f, false);
-    c = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, a.y), __builtin_bit_cast(f16x2, b.y), c, false);
-    c = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, a.z), __builtin_bit_cast(f16x2, b.z), c, false);
-    return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, a.w), __builtin_bit_cast(f16x2, b.w), c, false);
-}
 
 // Coalesced operand loads (COAL).  The matrix cores want lane (g, i16) to hold bytes 16 g .. 16 g + 15 of row i16's
 // 64-byte step, so a plain operand load has neighbouring lanes on 16 different rows: 64 cache look-ups per instruction.
@@ -2426,8 +2446,19 @@ void launch_scatter_results(const int32_t *list, int64_t n, int k, const int32_t
 // reduced to its distinct ids.  One workgroup per query: the ids go into an open-addressing table
 // in LDS (twice the list length, a power of two), then the occupied entries are written back over
 // the list (order does not matter: the rerank orders by score, then id).
+//
+// With `pr` (the forward lists after the scan) an entry is also left out when the query's FINAL threshold has passed
+// it by: it was forwarded under a looser threshold, and by the filter's guarantee - which holds for every valid
+// threshold, the final one included - a row the final threshold would not forward cannot be among the best k.  The
+// list keeps one number per entry, the scan's pessimistic bound v; what the scan tested is recovered from it on the
+// safe side with what holds for every tile of the handle (PruneParams):
+//   l2 fp16: v = sqrt(s_hi) + cxm(tile), s_hi = |q~|^2 (1 + c32) + 2.0005 c32 (1 - c32) |x~|^2 - 2 d (+ t2_hi), and the
+//            test was d >= A - (R + cxm)^2 / 2, i.e. R >= sqrt(2 (A - d)) - cxm with 2 (A - d) = s_hi - delta,
+//            delta <= 2 c32 |q~|^2 + 2.0005 c32 max|x~|^2 + 4e-6 (|q_t|^2 + max|x_t|^2);
+//   l2 int8: the same with delta = 1 (s_hi = |q'|^2 - 2 d_int + 1) and no rounding distances;
+//   dot:     v = q~.x~ - slack, forwarded while q~.x~ + slack >= tau, slack <= what the largest tile bounds give.
 __global__ __launch_bounds__(256) void k_unique_lists(int32_t *__restrict__ emit, const int32_t *__restrict__ emit_cnt, int32_t cap,
-                                                      int32_t *__restrict__ unique_cnt)
+                                                      int32_t *__restrict__ unique_cnt, PruneParams pr)
 {
     extern __shared__ int32_t tab[];
     __shared__ int32_t s_out;
@@ -2435,6 +2466,34 @@ __global__ __launch_bounds__(256) void k_unique_lists(int32_t *__restrict__ emit
     const int n = min(emit_cnt[q], cap);
     int32_t *list = emit + (size_t)q * cap;
     if (n <= 1) { if (threadIdx.x == 0) unique_cnt[q] = n; return; }
+    // per query: keep an entry iff v <= v_keep (l2) / v >= v_keep (dot)
+    float v_keep = pr.metric == 1 ? HUGE_VALF : -HUGE_VALF;
+    if (pr.emit_v) {
+        const float t_final = dec_f32(pr.tau[q]);
+        const bool i8 = pr.gate && *pr.gate == 0;
+        if (pr.metric == 1) {
+            // forwarded at the final radius iff sqrt(s_hi - delta) - cxm <= R, and sqrt(s_hi) >= (v - cx_max) (1 - 3e-6):
+            // keep iff (v - cx_max)(1 - 3e-6) <= sqrt((R + cx_max)^2 + delta), every rounding given to the keeping side
+            const float4 c = i8 ? pr.qc8[q] : pr.qc[q];
+            float delta;
+            if (i8) delta = 1.0f + 2e-6f * c.z;
+            else {
+                float qt2 = 0.f;
+                if (pr.q_tail) { const uint4 t = pr.q_tail[q]; qt2 = tail_dot(t, t); }
+                delta = (2.0f * pr.c32 * c.z + 2.0005f * pr.c32 * pr.xr_max * pr.xr_max + 4e-6f * (qt2 + pr.xt_max)) * 1.001f + 3e-6f * (c.z + pr.xr_max * pr.xr_max);
+            }
+            const float cx = pr.cx_max;
+            if (t_final < 3.0e37f) {
+                const float r = (t_final + cx) * 1.00001f;
+                v_keep = sqrtf(r * r + delta) * 1.00001f + cx * 1.00001f + 1e-30f;
+            }
+        } else {
+            // forwarded at the final product iff q~.x~ + slack >= tau; q~.x~ = v + slack (1.000001): keep iff v + 2.00001 slack_max >= tau
+            const float4 c = pr.qc[q];
+            const float slack = (c.y * pr.xr_max + (c.x + c.y) * pr.cx_max + pr.c32 * c.x * pr.xr_max) * 1.0001f + 1e-30f;
+            if (t_final > -3.0e37f) v_keep = t_final - 2.0001f * slack - fabsf(t_final) * 1e-5f - 1e-30f;
+        }
+    }
     int T = 2;
     while (T < 2 * n) T <<= 1;
     for (int i = threadIdx.x; i < T; i += 256) tab[i] = -1;
@@ -2442,6 +2501,10 @@ __global__ __launch_bounds__(256) void k_unique_lists(int32_t *__restrict__ emit
     __syncthreads();
     for (int i = threadIdx.x; i < n; i += 256) {
         const int32_t id = list[i];                       // ids are row numbers: never -1
+        if (pr.emit_v) {
+            const float v = pr.emit_v[(size_t)q * cap + i];
+            if (pr.metric == 1 ? v > v_keep : v < v_keep) continue;
+        }
         uint32_t h = ((uint32_t)id * 2654435761u) & (uint32_t)(T - 1);
         for (;;) {
             const int32_t old = atomicCAS(&tab[h], -1, id);
@@ -2476,12 +2539,14 @@ size_t unique_lists_lds(int32_t longest)
 // longest = the longest list of the batch (at most cap): it sizes the table, and with it how many
 // workgroups a CU holds
 void launch_unique_lists(int32_t *emit, const int32_t *emit_cnt, int32_t cap, int32_t longest, int32_t *unique_cnt, int64_t nq,
-                         hipStream_t stream)
+                         hipStream_t stream, const PruneParams *prune)
 {
     if (nq <= 0) return;
     const size_t T = unique_lists_lds(std::min(longest, cap)) / 4;
-    hipLaunchKernelGGL(k_unique_lists, dim3((unsigned)nq), dim3(256), (size_t)T * 4, stream, emit, emit_cnt, cap, unique_cnt);
+    const PruneParams pr = prune ? *prune : PruneParams();
+    hipLaunchKernelGGL(k_unique_lists, dim3((unsigned)nq), dim3(256), (size_t)T * 4, stream, emit, emit_cnt, cap, unique_cnt, pr);
 }
+float leafscan_c32_of(int stride) { return (5.0f * (float)(stride + 8) + 24.0f) * 5.9604645e-8f; }
 
 // ---------------------------------------------------------------------------
 // k_merge_topk: one thread per query merges `parts` sorted lists of k entries

@@ -1260,3 +1260,37 @@ def test_fp16_copies_are_taken_around_the_mean_row(dim, offset):
     assert np.array_equal(ii, si) and np.array_equal(is_, ss, equal_nan=True)
     for ix in (centred, plain, slow):
         ix.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("metric", ["l2", "dot"])
+@pytest.mark.parametrize("dim,kind", [(100, "plain"), (128, "integers"), (128, "offset"), (768, "plain"), (36, "near")])
+def test_rows_the_final_threshold_passed_by_are_dropped_safely(metric, dim, kind):
+    # before the exact rerank a forward list loses the entries the query's final threshold would no longer forward
+    # (recovered from the scan's one stored bound per entry with handle-wide maxima on the safe side);
+    # DPF_OPT_KEEP_FORWARDED scores every forwarded row: the same answers, and the gather path's
+    n, nq = (7000, 100) if dim <= 128 else (2500, 40)
+    if kind == "integers":
+        params, X, Q, pick = _integer_problem(n, nq, dim, 0, seed=5, bucket_overflow=50, table_num=2, permutation_num=2)
+    else:
+        params, X, Q, pick = make_problem(n=n, nq=nq, dim=dim, bucket_overflow=50, table_num=2, permutation_num=2, n_clusters=5)
+        if kind == "offset":
+            X = np.ascontiguousarray(X + np.float32(40.0)); Q = np.ascontiguousarray(Q + np.float32(40.0))
+        if kind == "near":                                          # many rows at (nearly) the k-th best distance
+            X[: n // 2] = X[n // 2: n // 2 * 2] + np.float32(1e-3) * np.random.default_rng(1).standard_normal((n // 2, dim), dtype=np.float32)
+    pick = pick.astype(np.int32)
+    pruned = DpfIndex(params, metric=metric)
+    kept = DpfIndex(params, metric=metric)
+    slow = DpfIndex(dict(params, flags=2), metric=metric)
+    for ix in (pruned, kept, slow):
+        ix.fit(X)
+    kept.set_option("keep_forwarded", 1)
+    for steps, k in ((1, 10), (2, 1), (0, 40)):
+        si, ss = slow.query_topk(pick, Q, steps=steps, k=k)
+        for ix in (pruned, kept):
+            for rep in range(2):                                    # sized on the host, then with carried sizes
+                ii, is_ = ix.query_topk(pick, Q, steps=steps, k=k)
+                assert ix.stats()["last_path"] == 1
+                assert np.array_equal(ii, si) and np.array_equal(is_, ss, equal_nan=True)
+    for ix in (pruned, kept, slow):
+        ix.close()
