@@ -223,23 +223,12 @@ __global__ __launch_bounds__(1024) void k_probe(ProbeParams p)
 
         // A wave works on two tables at a time: each lane then has four independent walks in flight (two
         // sub-indexes of each table), whose dependent 4-byte reads overlap.
-        // what is done with one lane's bucket (every lane calls it, with NO_LEAF when it has none)
+        // what modes 1 and 2 do with one lane's bucket (every lane calls it, with NO_LEAF when it has none; mode 0
+        // handles a lane's four buckets together, below)
         auto take = [&](uint32_t leaf, bool own_bucket) {
             uint32_t beg = 0, end = 0;
             if (leaf != NO_LEAF) { beg = p.leaf_off[leaf]; end = p.leaf_off[leaf + 1]; }
-            if (MODE == 0) {
-                raw_local += end - beg;
-                if (p.lq_cnt && end > beg) {
-                    // the old count is this query's place in the bucket's list
-                    const uint32_t place = atomicAdd(&p.lq_cnt[leaf], 1u);
-                    if (p.q_leaves) {
-                        const uint32_t pos = atomicAdd(&s_nleaf, 1u);
-                        // top bit: the bucket the query itself would be stored in (same sub-index, same path)
-                        if (pos < (uint32_t)p.q_leaf_cap)
-                            p.q_leaves[q * p.q_leaf_cap + pos] = make_uint2(leaf, place | (own_bucket ? 0x80000000u : 0u));
-                    }
-                }
-            } else if (MODE == 2) {
+            if (MODE == 2) {
                 if (end > beg) {
                     const uint32_t pos = atomicAdd(&p.lq_cursor[leaf], 1u);
                     p.leaf_queries[p.lq_off[leaf] + pos] = (int32_t)q;
@@ -364,7 +353,7 @@ __global__ __launch_bounds__(1024) void k_probe(ProbeParams p)
                     }
                 if constexpr (MODE == 0) {
                     // the four buckets of a lane together: their bounds in one round of loads, then the four
-                    // counter updates in flight at once (one after the other they were four dependent round trips)
+                    // counter updates in flight at once; the old count is the query's place in the bucket's list
                     uint32_t lb[4], le[4], place[4];
 #pragma unroll
                     for (int v = 0; v < 4; v++) {
