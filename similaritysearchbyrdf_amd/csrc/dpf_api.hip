@@ -1392,7 +1392,7 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
         lp.tickets += TICKET_COUNTERS * 32;               // every launch has its own counters
     }
     HIPCHECK(ix, ix->ws_ovf.ensure((size_t)nq * 4));
-    // one small kernel lists the overflowed queries and writes the batch's 32-byte record (flags + totals) straight
+    // one small kernel lists the overflowed queries and writes the batch's 40-byte record (flags, totals, int8 gate word) straight
     // into the pinned host words the host reads after the wait
     launch_overflow_list(emit_cnt_of(ix), nq, EMIT_CAP, flags, ix->ws_ovf.as<int32_t>(), (int32_t *)(ix->pinned + 4), stream);
     HIPCHECK(ix, hipStreamSynchronize(stream));
