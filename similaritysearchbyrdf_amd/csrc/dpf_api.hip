@@ -680,7 +680,12 @@ static int finish_fit(dpf_index *ix, int64_t total, int64_t new_rows)
         if (got[2] == 0 && std::isfinite(lo) && std::isfinite(hi) && hi - lo <= 255.0f && std::fabs(lo) <= 2048.0f && std::fabs(hi) <= 2048.0f) {
             i8_window = true;
             ix->ks8 = (d + 63) / 64;
-            ix->i8_offset = lo + 128.0f;
+            // The window [c - 128, c + 127]: the value range of unsigned or signed bytes when the rows lie inside one of
+            // them (queries of the same kind then always fit), else around the middle of the rows' range, so that queries
+            // a little outside that range on either side still fit.
+            if (lo >= 0.0f && hi <= 255.0f) ix->i8_offset = 128.0f;
+            else if (lo >= -128.0f && hi <= 127.0f) ix->i8_offset = 0.0f;
+            else ix->i8_offset = std::min(std::max(std::floor((lo + hi + 1.0f) * 0.5f), hi - 127.0f), lo + 128.0f);
         }
     }
     // l2 handles take their fp16 copies around the mean row: distances do not change, and the rounding distances of
