@@ -314,8 +314,12 @@ enum {
     DPF_OPT_EARLY_PASS_PERMILLE = 9, /* with 3 passes: share of the units in the first of them (40) */
     DPF_OPT_EXACT_SEEDS = 10,        /* 1: l2 handles score the seed sample exactly from the fp32 rows, as dot handles do
                                         (default 0: an upper bound of the k-th best distance from the fp16 copies) */
-    DPF_OPT_KEEP_FORWARDED = 11      /* 1: every row the scan forwarded is scored exactly (default 0: rows forwarded under a
+    DPF_OPT_KEEP_FORWARDED = 11,     /* 1: every row the scan forwarded is scored exactly (default 0: rows forwarded under a
                                         threshold the query has tightened past since are dropped before the exact rerank) */
+    DPF_OPT_SIDE_STREAM = 12         /* 0: every kernel of a batch is enqueued on the caller's stream (default 1: from the
+                                        handle's second batch on, the kernels that build the bucket lists run on a stream
+                                        of the handle's own beside those that find the first radii; both are ordered
+                                        behind the caller's stream and joined to it again before the scan) */
 };
 int dpf_set_option(dpf_index *ix, int32_t option, int64_t value);
 

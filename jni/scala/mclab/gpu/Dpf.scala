@@ -32,6 +32,8 @@ object Dpf {
   val OptScanPasses = 8
   val OptEarlyPassPermille = 9
   val OptExactSeeds = 10
+  val OptKeepForwarded = 11
+  val OptSideStream = 12
   // DPF_FLAG_* of dpf_config.flags
   val FlagHashOnly = 1
   val FlagGatherOnly = 2

@@ -191,6 +191,8 @@ struct dpf_index {
     DevBuf ws_compact;                                // the same lists packed back to back on the device
     bool sizes_carried = false;                       // a bucket-major batch has sized leaf_queries[] / units[] already
     hipEvent_t ev[6]{};
+    hipStream_t side_stream = nullptr;                // the list-building chain of a batch runs here, beside the first radii
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int last_path = 0;
     bool profiling = false;
     bool last_timed = false;                          // the last top-k batch recorded its events
@@ -203,7 +205,7 @@ struct dpf_index {
     int32_t opt_emit_cap = 0, opt_bucket_list_cap = 0, opt_first_permille = 100, opt_seed_cap = -1;   // seed sample: -1 = by the forest's bucket sizes
     int32_t auto_seed_cap = 256;             // what -1 stands for, set when the forest is built (seed_sample_for)
     int32_t opt_scan_passes = 0, opt_early_permille = 40;   // passes: 0 = by row length (3 from 16 steps on), 2 or 3
-    bool opt_sync_sizes = false, opt_short_rerank = true, opt_exact_seeds = false, opt_keep_forwarded = false;
+    bool opt_sync_sizes = false, opt_short_rerank = true, opt_exact_seeds = false, opt_keep_forwarded = false, opt_side_stream = true;
     int64_t opt_projection_min_rows = 4096;           // batches of at least this many vectors hash on the matrix cores (0: never)
 };
 
@@ -296,6 +298,9 @@ extern "C" int dpf_create(const dpf_config *cfg, dpf_index **out)
     if (e == hipSuccess) e = hipHostMalloc((void **)&ix->pinned, 12 * sizeof(int64_t), hipHostMallocDefault);
     for (int i = 0; i < 6 && e == hipSuccess; i++) e = hipEventCreate(&ix->ev[i]);
     for (int i = 0; i < 6 && e == hipSuccess; i++) e = hipEventCreate(&ix->ev_scan[i]);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ix->side_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ix->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ix->ev_join, hipEventDisableTiming);
     if (e != hipSuccess) {
         std::string m = std::string("dpf_create: ") + hipGetErrorString(e);
         delete ix;
@@ -345,6 +350,9 @@ extern "C" void dpf_destroy(dpf_index *ix)
     ix->ws_compact.release();
     for (int i = 0; i < 6; i++) if (ix->ev[i]) (void)hipEventDestroy(ix->ev[i]);
     for (int i = 0; i < 6; i++) if (ix->ev_scan[i]) (void)hipEventDestroy(ix->ev_scan[i]);
+    if (ix->ev_fork) (void)hipEventDestroy(ix->ev_fork);
+    if (ix->ev_join) (void)hipEventDestroy(ix->ev_join);
+    if (ix->side_stream) (void)hipStreamDestroy(ix->side_stream);
     DevBuf *more[] = {&ix->ws_emit_ucnt, &ix->ws_emit_v, &ix->ws_leaf_units, &ix->ws_unit_off, &ix->ws_q_leaves, &ix->ws_q_leaf_cnt, &ix->d_leaf_tile0, &ix->ws_units, &ix->d_tiles, &ix->ws_lq_off, &ix->ws_lq_cursor, &ix->ws_leaf_queries,
                       &ix->ws_seed_cand, &ix->ws_seed_cnt, &ix->ws_seed_ids, &ix->ws_seed_scores, &ix->ws_emit, &ix->ws_emit_cnt,
                       &ix->d_base16, &ix->ws_q16, &ix->d_base16n, &ix->ws_q16n, &ix->d_base16e, &ix->ws_q16e, &ix->ws_flag, &ix->ws_tau, &ix->ws_qc, &ix->d_slot_norm, &ix->d_base16t, &ix->d_slot_tail, &ix->ws_q16t, &ix->ws_ovf, &ix->d_base8, &ix->d_norm8, &ix->d_slot_nj8, &ix->d_i8_probe, &ix->ws_q8, &ix->ws_qc8, &ix->d_mu, &ix->d_bounds, &ix->sub_q, &ix->sub_qids, &ix->sub_ids,
@@ -1258,9 +1266,20 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     const int64_t cap_units = std::min<int64_t>((int64_t)(ix->ws_units.cap / 16), 0xfffffffell);
     int32_t *const flags = (int32_t *)flag_block_of(ix);
     int64_t *const d_totals = (int64_t *)(flag_block_of(ix) + 16);
+    // Behind the first probe pass a batch has two chains that meet again at the scan: the lists (offset scans,
+    // k_fill_lists, work units) and the first radii (seed sample, query conversions, k_seed_radius).  Neither reads what
+    // the other writes.  With carried sizes - nothing for the host to read in between - the list chain runs on the
+    // handle's side stream, beside the radii.
+    const bool fork = carried && ix->opt_side_stream && !ix->profiling && ix->side_stream != nullptr;
+    hipStream_t ls = stream;
+    if (fork) {
+        HIPCHECK(ix, hipEventRecord(ix->ev_fork, stream));
+        HIPCHECK(ix, hipStreamWaitEvent(ix->side_stream, ix->ev_fork, 0));
+        ls = ix->side_stream;
+    }
     launch_bucket_scans(lq_cnt_of(ix), ix->d_leaf_tile0.as<uint32_t>(), nl, ix->ws_lq_off.as<int64_t>(),
                         ix->ws_unit_off.as<int64_t>(), d_totals, carried, cap_pairs, cap_units, flags,
-                        ix->ws_lq_cursor.as<uint32_t>(), stream);
+                        ix->ws_lq_cursor.as<uint32_t>(), ls);
     int64_t pairs = 0, nunits = 0;
     bool lists_truncated = false;
     if (!carried) {
@@ -1284,7 +1303,13 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
         HIPCHECK(ix, hipMemsetAsync(ix->ws_lq_cursor.p, 0, (size_t)(nl + 1) * 4, stream));
         launch_probe(2, pp, nq, stream);
     }
-    else launch_fill_lists(pp, nq, stream);
+    else launch_fill_lists(pp, nq, ls);
+    if (!carried) HIPCHECK(ix, ix->ws_units.ensure((size_t)std::max<int64_t>(nunits + nunits / 2, 1024) * 16));
+    launch_units(lq_cnt_of(ix), ix->ws_lq_off.as<int64_t>(), ix->d_leaf_tile0.as<uint32_t>(),
+                 (const uint4 *)ix->d_tiles.p, ix->nutiles, ix->ws_unit_off.as<int64_t>(), (uint4 *)ix->ws_units.p,
+                 carried ? flags + 3 : nullptr, ls);
+    if (fork) HIPCHECK(ix, hipEventRecord(ix->ev_join, ls));
+    if (!lists_truncated) launch_seed_sample(pp, nq, stream);
     if (ix->profiling) HIPCHECK(ix, hipEventRecord(ix->ev[2], stream));
 
     // thresholds: exact top-k of each query's seed sample
@@ -1337,11 +1362,8 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
         launch_rows_to_i8((const float *)qpad, ix->dpad, ix->cfg.dim, nq, ix->i8_offset, ix->ws_q8.as<int8_t>(), ix->ks8 * 64, nullptr,
                           (float4 *)ix->ws_qc8.p, d_qids, i8_gate, stream);
     }
-    if (!carried) HIPCHECK(ix, ix->ws_units.ensure((size_t)std::max<int64_t>(nunits + nunits / 2, 1024) * 16));
-    launch_units(lq_cnt_of(ix), ix->ws_lq_off.as<int64_t>(), ix->d_leaf_tile0.as<uint32_t>(),
-                 (const uint4 *)ix->d_tiles.p, ix->nutiles, ix->ws_unit_off.as<int64_t>(), (uint4 *)ix->ws_units.p,
-                 carried ? flags + 3 : nullptr, stream);
     HIPCHECK(ix, ix->ws_emit_v.ensure((size_t)nq * EMIT_CAP * 4));
+    if (fork) HIPCHECK(ix, hipStreamWaitEvent(stream, ix->ev_join, 0));     // the scan needs both chains
     LeafScanParams lp;
     lp.ids = ix->d_ids.as<int32_t>();
     lp.leaf_queries = ix->ws_leaf_queries.as<int32_t>();
@@ -1797,6 +1819,9 @@ extern "C" int dpf_set_option(dpf_index *ix, int32_t option, int64_t value)
         return DPF_OK;
     case DPF_OPT_KEEP_FORWARDED:
         ix->opt_keep_forwarded = value != 0;
+        return DPF_OK;
+    case DPF_OPT_SIDE_STREAM:
+        ix->opt_side_stream = value != 0;
         return DPF_OK;
     case DPF_OPT_EXACT_SEEDS:
         ix->opt_exact_seeds = value != 0;

@@ -151,6 +151,7 @@ void launch_hash_mfma(int dtype, const void *X, int64_t x_stride, int64_t n, con
                       int32_t *hashes, int32_t *parts, hipStream_t stream);
 void launch_probe(int mode, const ProbeParams &p, int64_t nq, hipStream_t stream);
 void launch_fill_lists(const ProbeParams &p, int64_t nq, hipStream_t stream);
+void launch_seed_sample(const ProbeParams &p, int64_t nq, hipStream_t stream);
 void launch_leafscan(int metric, const LeafScanParams &p, hipStream_t stream);
 // flags[1] != 0 (a truncated bucket list) or a total beyond its capacity sets flags[3] when `guarded`
 void launch_bucket_scans(const uint32_t *lq_cnt, const uint32_t *leaf_tile0, int64_t nl, int64_t *lq_off, int64_t *unit_off,

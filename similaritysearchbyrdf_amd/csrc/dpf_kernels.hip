@@ -453,23 +453,16 @@ __global__ __launch_bounds__(1024) void k_probe(ProbeParams p)
     }
 }
 
-// k_fill_lists: what k_probe<2> does, from the bucket lists k_probe<0> recorded instead of a
-// second walk of the forest: write the query into its place in every bucket's list, copy the ids of the
-// first buckets into its seed sample.  Only launched when no query's list was truncated.
+// k_fill_lists + k_seed_sample: what k_probe<2> does, from the bucket lists k_probe<0> recorded instead of a
+// second walk of the forest.  k_fill_lists writes the query into its place in every bucket's list (it needs the
+// lists' offsets); k_seed_sample copies ids of the query's first buckets into its seed sample (it needs only what
+// k_probe<0> left, so the host may run it beside the offset scans).  Only launched when no query's list was truncated.
 __global__ __launch_bounds__(256) void k_fill_lists(ProbeParams p)
 {
-    __shared__ uint32_t s_seed, s_nown;
-    __shared__ uint32_t s_own[256], s_ob[256], s_oe[256];
     const int64_t q = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (p.abort && *p.abort) {                            // the lists have no room for this batch: it is run again
-        if (tid == 0) p.seed_cnt[q] = 0;
-        return;
-    }
+    const int tid = threadIdx.x;
+    if (p.abort && *p.abort) return;                      // the lists have no room for this batch: it is run again
     const int n = min(p.q_leaf_cnt[q], p.q_leaf_cap);
-    const int32_t qid = p.qids ? p.qids[q] : -1;
-    if (tid == 0) { s_seed = 0; s_nown = 0; }
-    __syncthreads();
     const uint2 *mine = p.q_leaves + q * p.q_leaf_cap;
     for (int j0 = tid; j0 < n; j0 += 1024) {
         // four entries per thread and round: the entries, then their buckets' list offsets, in flight together
@@ -483,10 +476,27 @@ __global__ __launch_bounds__(256) void k_fill_lists(ProbeParams p)
         for (int u = 0; u < 4; u++) {
             if (j0 + 256 * u >= n) continue;
             p.leaf_queries[off[u] + (lp[u].y & 0x7fffffffu)] = (int32_t)q;
-            if (lp[u].y & 0x80000000u) {
-                const uint32_t at = atomicAdd(&s_nown, 1u);
-                if (at < 256u) s_own[at] = lp[u].x;
-            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_seed_sample(ProbeParams p)
+{
+    __shared__ uint32_t s_seed, s_nown;
+    __shared__ uint32_t s_own[256], s_ob[256], s_oe[256];
+    const int64_t q = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = min(p.q_leaf_cnt[q], p.q_leaf_cap);
+    const int32_t qid = p.qids ? p.qids[q] : -1;
+    if (tid == 0) { s_seed = 0; s_nown = 0; }
+    __syncthreads();
+    const uint2 *mine = p.q_leaves + q * p.q_leaf_cap;
+    // the query's own buckets: the entries k_probe<0> flagged
+    for (int j = tid; j < n; j += 256) {
+        const uint2 e = mine[j];
+        if (e.y & 0x80000000u) {
+            const uint32_t at = atomicAdd(&s_nown, 1u);
+            if (at < 256u) s_own[at] = e.x;
         }
     }
     __syncthreads();
@@ -540,6 +550,11 @@ __global__ __launch_bounds__(256) void k_fill_lists(ProbeParams p)
         if (!(mine[j].y & 0x80000000u)) copy_from(mine[j].x, 0xffffffffu);
     __syncthreads();
     if (tid == 0) p.seed_cnt[q] = s_seed < (uint32_t)p.seed_cap ? (int32_t)s_seed : p.seed_cap;
+}
+
+void launch_seed_sample(const ProbeParams &p, int64_t nq, hipStream_t stream)
+{
+    if (nq > 0) hipLaunchKernelGGL(k_seed_sample, dim3((unsigned)nq), dim3(256), 0, stream, p);
 }
 
 void launch_fill_lists(const ProbeParams &p, int64_t nq, hipStream_t stream)

@@ -1294,3 +1294,41 @@ def test_rows_the_final_threshold_passed_by_are_dropped_safely(metric, dim, kind
                 assert np.array_equal(ii, si) and np.array_equal(is_, ss, equal_nan=True)
     for ix in (pruned, kept, slow):
         ix.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["plain", "integers"])
+def test_list_chain_on_the_side_stream_changes_nothing(kind):
+    # from a handle's second batch on the kernels that build the bucket lists run on a stream of the handle's own, beside
+    # those that find the first radii (DPF_OPT_SIDE_STREAM, default 1): the same answers as with one stream, on torch's
+    # default stream and on another one, over batches of changing size
+    import torch
+    if kind == "integers":
+        params, X, Q, pick = _integer_problem(9000, 300, 128, 0, seed=11, bucket_overflow=50, table_num=3, permutation_num=2)
+    else:
+        params, X, Q, pick = make_problem(n=9000, nq=300, dim=100, bucket_overflow=50, table_num=3, permutation_num=2, n_clusters=6)
+    pick = pick.astype(np.int32)
+    two = DpfIndex(params, metric="l2")
+    one = DpfIndex(params, metric="l2")
+    for ix in (two, one):
+        ix.fit(X)
+    one.set_option("side_stream", 0)
+    dev = torch.device("cuda", 0)
+    dQ, dp = torch.from_numpy(Q).to(dev), torch.from_numpy(pick).to(dev)
+    other = torch.cuda.Stream(device=dev)
+    k = 10
+    for rep, nq in enumerate((300, 300, 120, 300, 7, 300)):
+        want_i, want_s = one.query_topk(pick[:nq], Q[:nq], steps=1, k=k)
+        got_i, got_s = two.query_topk(pick[:nq], Q[:nq], steps=1, k=k)
+        assert two.stats()["last_path"] == 1
+        assert np.array_equal(got_i, want_i) and np.array_equal(got_s, want_s, equal_nan=True)
+        # the device entry point on a stream that is not the default one
+        ids = torch.full((nq, k), -7, dtype=torch.int32, device=dev)
+        sc = torch.zeros((nq, k), dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(other):
+            two.query_topk_device(dp.data_ptr(), dQ.data_ptr(), nq, 1, k, ids.data_ptr(), sc.data_ptr(), other.cuda_stream)
+        other.synchronize()
+        assert np.array_equal(ids.cpu().numpy(), want_i) and np.array_equal(sc.cpu().numpy(), want_s, equal_nan=True)
+    for ix in (two, one):
+        ix.close()
