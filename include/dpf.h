@@ -203,7 +203,9 @@ int dpf_query_topk(dpf_index *ix, const int32_t *qids, const void *Q, int64_t nq
  * sizes and overflow flags, may grow the handle's workspaces (hipMalloc / hipFree), and runs a batch
  * again when the buffers carried from earlier batches turn out too small.  On return the last
  * kernels of the batch (the exact rerank writing d_ids / d_scores) may still be running on `stream`:
- * order later work on that stream, or synchronise it, before reading the results. */
+ * order later work on that stream, or synchronise it, before reading the results.  (Some kernels
+ * of a batch run on a stream of the handle's own, forked from `stream` and joined to it again with
+ * events inside the call: DPF_OPT_SIDE_STREAM.) */
 int dpf_query_topk_device(dpf_index *ix, const int32_t *d_qids, const void *d_Q, int64_t nq,
                           int32_t steps, int32_t k, int32_t *d_ids, double *d_scores, void *stream);
 
