@@ -302,7 +302,7 @@ enum {
                                         doubled up to 65536 after a batch in which a list overflowed) */
     DPF_OPT_BUCKET_LIST_CAP = 2,     /* buckets remembered per query by the first probe pass (default: up to 4096) */
     DPF_OPT_SYNC_SIZES = 3,          /* 1: the host reads every batch's list sizes before filling the lists */
-    DPF_OPT_FIRST_PASS_PERMILLE = 4, /* share of the scan's work units run before the thresholds are refined (100) */
+    DPF_OPT_FIRST_PASS_PERMILLE = 4, /* share of the scan's work units run before the thresholds are refined (150) */
     DPF_OPT_SEED_SAMPLE = 5,         /* candidates per query whose distances give the first thresholds: 16..4096, 0 = none, or
                                         -1 (default) = chosen at every fit from the forest's bucket sizes: 5 sqrt(tables x
                                         size-biased mean bucket size), within [128, 2048] */

@@ -202,7 +202,7 @@ struct dpf_index {
     int32_t probe_mode = DPF_PROBE_FLIPS;             // dpf_set_probe_mode
     unsigned char *scratch_ptr = nullptr;             // this device's copy of the static scratch array
     // dpf_set_option values (0 / default = the library's own choice)
-    int32_t opt_emit_cap = 0, opt_bucket_list_cap = 0, opt_first_permille = 100, opt_seed_cap = -1;   // seed sample: -1 = by the forest's bucket sizes
+    int32_t opt_emit_cap = 0, opt_bucket_list_cap = 0, opt_first_permille = 150, opt_seed_cap = -1;   // seed sample: -1 = by the forest's bucket sizes
     int32_t auto_seed_cap = 256;             // what -1 stands for, set when the forest is built (seed_sample_for)
     int32_t opt_scan_passes = 0, opt_early_permille = 40;   // passes: 0 = by row length (3 from 16 steps on), 2 or 3
     bool opt_sync_sizes = false, opt_short_rerank = true, opt_exact_seeds = false, opt_keep_forwarded = false, opt_side_stream = true;
@@ -1381,7 +1381,7 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     if (ix->filter_dim < ix->cfg.dim) { lp.slot_tail = (const uint4 *)ix->d_slot_tail.p; lp.q_tail = (const uint4 *)ix->ws_q16t.p; }
     lp.num_counters = TICKET_COUNTERS;
     lp.tickets = (unsigned int *)(flag_block_of(ix) + 128);
-    // Slices of the units with the thresholds refined from what has been forwarded in between: a first tenth, then the
+    // Slices of the units with the thresholds refined from what has been forwarded in between: a first 15 %, then the
     // rest; for long rows (one wave per SIMD: nothing hides the cost of a forwarded row) a fiftieth goes before them.
     const int first_permille = ix->opt_first_permille;
     const int passes = ix->opt_scan_passes ? ix->opt_scan_passes : (ix->ks16 >= 16 ? 3 : 2);
