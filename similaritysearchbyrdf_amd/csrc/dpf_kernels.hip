@@ -1349,7 +1349,7 @@ __device__ __forceinline__ void leafscan_chunks(const LeafScanParams &p, const u
                                                 const typename ScanTypes<I8>::val (&nJ)[RB], const int32_t (&idj)[RB], uint32_t rows, uint32_t nq,
                                                 uint32_t lq0, float xrm, float cxm, int32_t qsc, int32_t qsn, int32_t *s_fq,
                                                 int32_t *s_fid, float *s_fv, float4 *s_slot, float *s_G, int32_t *s_qid, int &nbuf,
-                                                const uint4 *s_xt, uint4 *s_qt, float *s_qt2)
+                                                const uint4 *s_xt, uint4 *s_qt, float *s_qt2, float *s_sel)
 {
     static_assert(!TAIL || METRIC == 1, "tails belong to the l2 filter");
     static_assert(RB == 4 || RB == 1, "64-row tiles, or 16-row tiles for rows of more than 768 dimensions");
@@ -1578,39 +1578,48 @@ __device__ __forceinline__ void leafscan_chunks(const LeafScanParams &p, const u
 #pragma unroll
                 for (int o = 1; o < 16; o <<= 1) tight += __shfl_xor(tight, o);
             }
-            if (METRIC == 1 && tight >= p.k && !DPF_ABLATION(p, 4)) {
-                // Roughly k or more rows of this tile sit inside 0.985 of the k-th best distance.  With
+            if (METRIC == 1 && !DPF_ABLATION(p, 4) && __ballot(tight >= p.k) != 0) {
+                // Roughly k or more rows of this tile sit inside 0.985 of the k-th best distance (in some 16-lane group:
+                // the wave goes through this together, groups below k take no part).  With
                 //   v = sqrt(s_hi) + |x - x~|max >= sqrt(exact distance) - |q - q~|
-                // the k-th smallest v among the RB*16 rows this 16-lane group holds for the query bounds
-                // the query's k-th best distance from above, and R = that + 2 |q - q~| is a new radius.
-                float v[RB];
+                // the k-th smallest v among those rows bounds the query's k-th best distance from above (the k-th
+                // smallest of any k or more of its rows does), and R = that + 2 |q - q~| is a new radius.
+                const bool grp_on = tight >= p.k;
+                // (lane-derived values of this rare path are made here, from a copy of the lane number the compiler cannot
+                // trace: hoisted out of the chunk loop they would cost the whole kernel three registers)
+                int l2 = lane;
+                asm volatile("" : "+v"(l2));
+                const int g2 = l2 >> 4, i2 = l2 & 15;
+                float *const sel = s_sel + 64 * g2;
+                // the group's rows inside the trigger level, packed into its 64 slots of s_sel in (row block, lane) order
+                int m_g = 0;
 #pragma unroll
                 for (int rb = 0; rb < RB; rb++) {
-                    const bool ok = idj[rb] >= 0 && !self_excluded(idj[rb], qidq, p.exclude_self);
                     float t2lo, t2hi;
                     tail2(rb, t2lo, t2hi);
+                    const float d2 = fmaf(-0.5f, t2lo, (float)acc[rb][r]);
+                    const bool mem = grp_on && idj[rb] >= 0 && acc[rb][r] >= Gr && d2 >= sc.x && !self_excluded(idj[rb], qidq, p.exclude_self);
                     float s_hi;
                     if constexpr (I8) s_hi = fmaf(-2.0f, (float)acc[rb][r], sc.w) + 1.0f;
                     else s_hi = fmaf(-2.0f, acc[rb][r], sc.w * (1.0f + c32) - 4.001f * c32 * nJ[rb]) + t2hi;
-                    v[rb] = ok ? sqrtf(fmaxf(s_hi, 0.f) * 1.000001f) * 1.000001f + cxm : HUGE_VALF;
+                    const uint32_t bits = (uint32_t)(__ballot(mem) >> (16 * g2)) & 0xffffu;
+                    if (mem) sel[m_g + __popc(bits & ((1u << i2) - 1u))] = s_hi;     // (v grows with s_hi: ranked as it is)
+                    m_g += __popc(bits);
                 }
-                // rank of each of this lane's RB values among the group's 16*RB, one value at a time: the path
-                // is rare, and keeping four ranks at once costs registers the whole kernel would pay for
-#pragma nounroll
-                for (int mb = 0; mb < RB; mb++) {
-                    const float mine = mb == 0 ? v[0] : mb == 1 ? v[1 % RB] : mb == 2 ? v[2 % RB] : v[3 % RB];
+                // every packed value finds its rank among the group's: 16 values per round, one LDS broadcast per comparison
+                for (int r0 = 0; __ballot(r0 < m_g) != 0; r0 += 16) {
+                    const int my = r0 + i2;
+                    const bool have = my < m_g;
+                    const float mine = have ? sel[my] : HUGE_VALF;
                     int rank = 0;
-#pragma nounroll
-                    for (int j = 0; j < 16; j++) {
-                        const int src = 16 * g + j;
-#pragma unroll
-                        for (int ob = 0; ob < RB; ob++) {
-                            const float o = __shfl(v[ob], src);
-                            rank += (o < mine || (o == mine && (j < i16 || (j == i16 && ob < mb)))) ? 1 : 0;
-                        }
+                    for (int i = 0; __ballot(i < m_g) != 0; i++) {
+                        const float o = i < m_g ? sel[i] : HUGE_VALF;
+                        rank += (o < mine || (o == mine && i < my)) ? 1 : 0;
                     }
-                    if (rank == p.k - 1 && mine < HUGE_VALF)
-                        atomicMin(&p.tau[qq], enc_f32((mine + 2.0f * sc.z) * 1.000002f));
+                    if (have && rank == p.k - 1) {
+                        const float v = sqrtf(fmaxf(mine, 0.f) * 1.000001f) * 1.000001f + cxm;
+                        atomicMin(&p.tau[qq], enc_f32((v + 2.0f * sc.z) * 1.000002f));
+                    }
                 }
             }
         }
@@ -1655,6 +1664,7 @@ __device__ __forceinline__ void leafscan_body(const LeafScanParams &p, const uin
     __shared__ float4 s_slot[4][16];
     __shared__ __attribute__((aligned(16))) float s_G[4][16];
     __shared__ int32_t s_qid[4][16];
+    __shared__ float s_sel[4][METRIC == 1 ? 256 : 1];       // in-tile tightening: the rows of each 16-lane group inside the trigger level
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // Units are handed out dynamically, so that a wave that drew long units takes fewer: NC ticket counters,
@@ -1775,7 +1785,7 @@ __device__ __forceinline__ void leafscan_body(const LeafScanParams &p, const uin
         if (lane == 0) pend = atomicAdd(ctr, 1u);
         small(U0, id0, qs0);
         leafscan_chunks<KS, METRIC, RB, TAIL, I8, COAL>(p, Q16, xb, nJ, idj, rows, nq, lq0, xrm, cxm, qsc, qsn, s_fq[wave], s_fid[wave], s_fv[wave],
-                                              s_slot[wave], s_G[wave], s_qid[wave], nbuf, s_xt[wave], s_qt[wave], s_qt2[wave]);
+                                              s_slot[wave], s_G[wave], s_qid[wave], nbuf, s_xt[wave], s_qt[wave], s_qt2[wave], s_sel[wave]);
     }
     leafscan_flush_rest(p, s_fq[wave], s_fid[wave], s_fv[wave], nbuf);
 }
