@@ -1362,8 +1362,10 @@ __device__ __forceinline__ void leafscan_chunks(const LeafScanParams &p, const u
     // Rows of more than 8 steps: a 64-row tile still pays (one wave per SIMD holds it in the 512 registers
     // of its lanes; sharing a tile's rows among 4x the queries outweighs the lost occupancy: 1.4-1.5x
     // faster than 16-row tiles at 512 and 768 dimensions); beyond 24 steps only 16 rows fit (RB == 1).
-    // Their query rows come in slices of QS steps.
-    constexpr int QS = KS > 8 ? (RB == 4 ? 4 : 8) : KS;
+    // Their query rows come in slices of QS steps, as long as the registers allow without spilling: a wave alone on its
+    // SIMD waits out every slice's round trip (768 dimensions, slices of 4 / 6 / 8 steps: 5.72 / 5.27 / 5.46 ms per
+    // launch on 1.25 M rows - the last one spills; 512 dimensions hold the whole query row: 3.63 -> 3.49 ms).
+    constexpr int QS = KS > 8 ? (RB == 4 ? (KS == 16 ? 16 : 6) : 8) : KS;
     static_assert(KS % QS == 0, "whole slices");
     const int lane = threadIdx.x & 63;
     const int i16 = lane & 15, g = lane >> 4;
