@@ -1351,7 +1351,7 @@ __device__ __forceinline__ void leafscan_chunks(const LeafScanParams &p, const u
                                                 const typename ScanTypes<I8>::val (&nJ)[RB], const int32_t (&idj)[RB], uint32_t rows, uint32_t nq,
                                                 uint32_t lq0, float xrm, float cxm, int32_t qsc, int32_t qsn, int32_t *s_fq,
                                                 int32_t *s_fid, float *s_fv, float4 *s_slot, float *s_G, int32_t *s_qid, int &nbuf,
-                                                const uint4 *s_xt, uint4 *s_qt, float *s_qt2, float *s_sel)
+                                                const uint4 *s_xt, uint4 *s_qt, float *s_qt2, float *s_sel, uint4 *s_q)
 {
     static_assert(!TAIL || METRIC == 1, "tails belong to the l2 filter");
     static_assert(RB == 4 || RB == 1, "64-row tiles, or 16-row tiles for rows of more than 768 dimensions");
@@ -1365,8 +1365,13 @@ __device__ __forceinline__ void leafscan_chunks(const LeafScanParams &p, const u
     // Their query rows come in slices of QS steps, as long as the registers allow without spilling: a wave alone on its
     // SIMD waits out every slice's round trip (768 dimensions, slices of 4 / 6 / 8 steps: 5.72 / 5.27 / 5.46 ms per
     // launch on 1.25 M rows - the last one spills; 512 dimensions hold the whole query row: 3.63 -> 3.49 ms).
-    constexpr int QS = KS > 8 ? (RB == 4 ? (KS == 16 ? 16 : 6) : 8) : KS;
+    constexpr int QS = KS > 8 ? (RB == 4 ? (KS == 16 ? 16 : 4) : 8) : KS;
     static_assert(KS % QS == 0, "whole slices");
+    // Rows of more than 16 steps: the chunk's 16 query rows are fetched whole into the wave's own LDS block by
+    // global_load_lds (no registers; lane quad m fetches the 64 bytes of step t of the query in operand row m, so
+    // instruction t fills the 1 KiB block of step t and lane (m, g) later reads slot 4 m + g of it: conflict-free) and
+    // the slices come from there: one memory round trip per chunk instead of one per slice.
+    constexpr bool QLDS = !I8 && RB == 4 && KS > 16;
     const int lane = threadIdx.x & 63;
     const int i16 = lane & 15, g = lane >> 4;
     const uint32_t jq = 4u * (uint32_t)(i16 & 3) + (uint32_t)(i16 >> 2);   // chunk position of this lane's MFMA row
@@ -1383,11 +1388,21 @@ __device__ __forceinline__ void leafscan_chunks(const LeafScanParams &p, const u
         }
     };
 
+    // (QLDS) the 16 query rows named by `qs` (lane i16 holds operand row i16's query) on their way into the wave's LDS block
+    auto stage_queries = [&](int32_t qs) {
+        const int32_t ql = __shfl(qs, lane >> 2);
+        const uint16_t *qr = Q16 + (size_t)(ql >= 0 ? ql : 0) * STRIDE + 8 * (lane & 3);
+#pragma unroll
+        for (int t = 0; t < KS; t++)
+            __builtin_amdgcn_global_load_lds(qr + 32 * t, (__attribute__((address_space(3))) void *)(s_q + 64 * t), 16, 0, 0);
+    };
     for (uint32_t c = 0; c < nq; c += 16u) {
         f16x8 qa[QS];
         const size_t qat = (size_t)(qsc >= 0 ? qsc : 0);
         const uint16_t *qrow = Q16 + (DPF_ABLATION(p, 2) ? (qat & 15) : qat) * STRIDE + 8 * g;   // debug 2: all query rows from one hot spot (timing only)
-        if constexpr (COAL) {
+        if constexpr (QLDS) {
+            if (c == 0) stage_queries(qsc);               // (later chunks: requested while the chunk before them was finishing)
+        } else if constexpr (COAL) {
             // quad j reads the query at chunk position j; operand row i16 then holds position pi(i16) = jq
             const int lj = lane >> 2;
             const int32_t ql = __shfl(qsc, 4 * (lj & 3) + (lj >> 2));
@@ -1476,7 +1491,14 @@ __device__ __forceinline__ void leafscan_chunks(const LeafScanParams &p, const u
 #else
 #pragma unroll
             for (int s0 = 0; s0 < KS; s0 += QS) {
-                if (s0 > 0) {
+                if constexpr (QLDS) {
+                    if (s0 == 0) {
+                        __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): the chunk's query rows have landed in LDS
+                        asm volatile("" ::: "memory");
+                    }
+#pragma unroll
+                    for (int t = 0; t < QS; t++) qa[t] = __builtin_bit_cast(f16x8, s_q[64 * (s0 + t) + 4 * i16 + g]);
+                } else if (s0 > 0) {
 #pragma unroll
                     for (int t = 0; t < QS; t++) qa[t] = *(const f16x8 *)(qrow + 32 * (s0 + t));
                 }
@@ -1485,6 +1507,13 @@ __device__ __forceinline__ void leafscan_chunks(const LeafScanParams &p, const u
                     if (rb * 16u >= rows && rb > 0) continue;
 #pragma unroll
                     for (int t = 0; t < QS; t++) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qa[t], xb[rb][s0 + t], acc[rb], 0, 0, 0);
+                }
+            }
+            if constexpr (QLDS) {
+                // the block has been read out: the next chunk's rows are requested now, beside this chunk's last products and tests
+                if (c + 16u < nq) {
+                    __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): the last slice has left LDS
+                    stage_queries(qsc);
                 }
             }
 #endif
@@ -1668,6 +1697,7 @@ __device__ __forceinline__ void leafscan_body(const LeafScanParams &p, const uin
     __shared__ float4 s_slot[4][16];
     __shared__ __attribute__((aligned(16))) float s_G[4][16];
     __shared__ int32_t s_qid[4][16];
+    extern __shared__ uint4 s_dyn[];                      // rows of more than 16 steps: 16 whole query rows per wave
     __shared__ float s_sel[4][METRIC == 1 ? 256 : 1];       // in-tile tightening: the rows of each 16-lane group inside the trigger level
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1789,7 +1819,8 @@ __device__ __forceinline__ void leafscan_body(const LeafScanParams &p, const uin
         if (lane == 0) pend = atomicAdd(ctr, 1u);
         small(U0, id0, qs0);
         leafscan_chunks<KS, METRIC, RB, TAIL, I8, COAL>(p, Q16, xb, nJ, idj, rows, nq, lq0, xrm, cxm, qsc, qsn, s_fq[wave], s_fid[wave], s_fv[wave],
-                                              s_slot[wave], s_G[wave], s_qid[wave], nbuf, s_xt[wave], s_qt[wave], s_qt2[wave], s_sel[wave]);
+                                              s_slot[wave], s_G[wave], s_qid[wave], nbuf, s_xt[wave], s_qt[wave], s_qt2[wave], s_sel[wave],
+                                              s_dyn + (size_t)wave * (KS * 64));
     }
     leafscan_flush_rest(p, s_fq[wave], s_fid[wave], s_fv[wave], nbuf);
 }
@@ -1808,6 +1839,9 @@ __global__ __launch_bounds__(256, ls16_waves(KS, 4, true)) void k_leafscan_i8(Le
     leafscan_body<KS, 1, 4, false, true, LS8_COAL != 0>(p, Q8, B8);
 }
 
+// dynamic LDS of the scan: the staged query rows of the forms with more than 16 steps (4 waves x 16 rows x KS x 64 bytes)
+constexpr size_t leafscan_dyn_lds(int ks, int rb) { return rb == 4 && ks > 16 ? (size_t)4 * ks * 1024 : 0; }
+
 template <int METRIC, int RB>
 static void launch_leafscan_f16_m(const LeafScanParams &p, hipStream_t stream)
 {
@@ -1820,9 +1854,9 @@ static void launch_leafscan_f16_m(const LeafScanParams &p, hipStream_t stream)
 #define DPF_LB(KS)                                                                                                       \
     do {                                                                                                                 \
         if constexpr (METRIC == 1) {                                                                                     \
-            if (q.slot_tail) { hipLaunchKernelGGL((k_leafscan_f16<KS, METRIC, RB, true>), grid, block, 0, stream, q, q.Q16, q.base16); break; } \
+            if (q.slot_tail) { hipLaunchKernelGGL((k_leafscan_f16<KS, METRIC, RB, true>), grid, block, leafscan_dyn_lds(KS, RB), stream, q, q.Q16, q.base16); break; } \
         }                                                                                                                \
-        hipLaunchKernelGGL((k_leafscan_f16<KS, METRIC, RB, false>), grid, block, 0, stream, q, q.Q16, q.base16);         \
+        hipLaunchKernelGGL((k_leafscan_f16<KS, METRIC, RB, false>), grid, block, leafscan_dyn_lds(KS, RB), stream, q, q.Q16, q.base16);         \
     } while (0)
     if constexpr (RB == 4 && METRIC == 1) {
         if (p.i8) {
@@ -2626,6 +2660,14 @@ int configure_kernels()
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute((const void *)k_probe<1>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
     if (e != hipSuccess) return (int)e;
+    {
+        const void *long_rows[] = {(const void *)k_leafscan_f16<24, 0, 4, false>, (const void *)k_leafscan_f16<24, 1, 4, false>,
+                                   (const void *)k_leafscan_f16<24, 1, 4, true>};
+        for (const void *f : long_rows) {
+            e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)leafscan_dyn_lds(24, 4));
+            if (e != hipSuccess) return (int)e;
+        }
+    }
     e = hipFuncSetAttribute((const void *)k_unique_lists, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
     if (e != hipSuccess) return (int)e;
     return 0;
