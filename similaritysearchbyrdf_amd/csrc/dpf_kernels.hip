@@ -1365,13 +1365,13 @@ __device__ __forceinline__ void leafscan_chunks(const LeafScanParams &p, const u
     // Their query rows come in slices of QS steps, as long as the registers allow without spilling: a wave alone on its
     // SIMD waits out every slice's round trip (768 dimensions, slices of 4 / 6 / 8 steps: 5.72 / 5.27 / 5.46 ms per
     // launch on 1.25 M rows - the last one spills; 512 dimensions hold the whole query row: 3.63 -> 3.49 ms).
-    constexpr int QS = KS > 8 ? (RB == 4 ? (KS == 16 ? 16 : 4) : 8) : KS;
+    constexpr int QS = KS > 8 ? (RB == 4 ? 4 : 8) : KS;
     static_assert(KS % QS == 0, "whole slices");
     // Rows of more than 16 steps: the chunk's 16 query rows are fetched whole into the wave's own LDS block by
     // global_load_lds (no registers; lane quad m fetches the 64 bytes of step t of the query in operand row m, so
     // instruction t fills the 1 KiB block of step t and lane (m, g) later reads slot 4 m + g of it: conflict-free) and
     // the slices come from there: one memory round trip per chunk instead of one per slice.
-    constexpr bool QLDS = !I8 && RB == 4 && KS > 16;
+    constexpr bool QLDS = !I8 && RB == 4 && KS > 8;
     const int lane = threadIdx.x & 63;
     const int i16 = lane & 15, g = lane >> 4;
     const uint32_t jq = 4u * (uint32_t)(i16 & 3) + (uint32_t)(i16 >> 2);   // chunk position of this lane's MFMA row
@@ -1840,7 +1840,7 @@ __global__ __launch_bounds__(256, ls16_waves(KS, 4, true)) void k_leafscan_i8(Le
 }
 
 // dynamic LDS of the scan: the staged query rows of the forms with more than 16 steps (4 waves x 16 rows x KS x 64 bytes)
-constexpr size_t leafscan_dyn_lds(int ks, int rb) { return rb == 4 && ks > 16 ? (size_t)4 * ks * 1024 : 0; }
+constexpr size_t leafscan_dyn_lds(int ks, int rb) { return rb == 4 && ks > 8 ? (size_t)4 * ks * 1024 : 0; }
 
 template <int METRIC, int RB>
 static void launch_leafscan_f16_m(const LeafScanParams &p, hipStream_t stream)
@@ -2662,7 +2662,8 @@ int configure_kernels()
     if (e != hipSuccess) return (int)e;
     {
         const void *long_rows[] = {(const void *)k_leafscan_f16<24, 0, 4, false>, (const void *)k_leafscan_f16<24, 1, 4, false>,
-                                   (const void *)k_leafscan_f16<24, 1, 4, true>};
+                                   (const void *)k_leafscan_f16<24, 1, 4, true>, (const void *)k_leafscan_f16<16, 0, 4, false>,
+                                   (const void *)k_leafscan_f16<16, 1, 4, false>, (const void *)k_leafscan_f16<16, 1, 4, true>};
         for (const void *f : long_rows) {
             e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)leafscan_dyn_lds(24, 4));
             if (e != hipSuccess) return (int)e;
