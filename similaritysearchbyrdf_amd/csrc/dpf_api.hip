@@ -503,8 +503,10 @@ static int hash_rows(dpf_index *ix, const void *X, int64_t stride, int64_t n, in
 // stored row - or a query near one - falls into) the own buckets hold about T * m rows over the T tables this handle
 // probes, and the sample is 5 sqrt(T m), at least 128 and at most 2048, a multiple of 64.  Measured optima this rule
 // has to meet (batch time against sample size): one tree of 1M clustered 100-d rows (T m = 172): 128; 30 trees of
-// 768-d rows (3.4 k): 256; 30 trees of 100-d rows (5.9 k): 256-384; 30 trees of SIFT-shaped rows (58 k, buckets of up
-// to 31 k rows): 1024-2048, where 256 is 18 % slower.
+// 100-d rows (5.9 k): 256-384; 30 trees of SIFT-shaped rows (58 k, buckets of up to 31 k rows): 1024-2048, where 256 is
+// 18 % slower.  Rows of 16 steps and more (512 dimensions up) take 1.5 sqrt(T m), at least 64: a seed costs as many bytes
+// as a scanned row there, and their three scan slices with a refinement after each make up for weaker first thresholds
+// (30 trees of 768-d rows, T m = 3.4 k: 96 / 128 / 192 / 256 / 384 / 512 -> 15.99 / 16.04 / 16.22 / 16.44 / 16.78 / 17.16 ms).
 static int32_t seed_sample_for(const dpf_index *ix)
 {
     double s1 = 0, s2 = 0;
@@ -512,9 +514,10 @@ static int32_t seed_sample_for(const dpf_index *ix)
     if (s1 <= 0) return 256;
     const int t_end = ix->cfg.table_end > 0 ? ix->cfg.table_end : ix->cfg.num_tables;
     const int tables = std::max(1, t_end - ix->cfg.table_begin);
-    const double want = 5.0 * std::sqrt((double)tables * (s2 / s1));
+    const bool long_rows = ix->ks16 >= 16;
+    const double want = (long_rows ? 1.5 : 5.0) * std::sqrt((double)tables * (s2 / s1));
     const int64_t v = ((int64_t)want + 63) / 64 * 64;
-    return (int32_t)std::min<int64_t>(2048, std::max<int64_t>(128, v));
+    return (int32_t)std::min<int64_t>(2048, std::max<int64_t>(long_rows ? 64 : 128, v));
 }
 
 static int upload_snapshot(dpf_index *ix, ForestSnapshot &s)
