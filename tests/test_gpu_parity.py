@@ -803,7 +803,7 @@ def test_overflowed_queries_take_the_gather_path_alone(metric, with_qids):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", range(48))
-def test_random_configurations(seed):
+def test_random_configurations(seed, dims=(8, 33, 64, 100, 130, 256)):
     # a seeded draw over the configuration space: hash family, index transform, trie geometry, overflow
     # threshold, dimension, metric, k, search steps; scan path == gather path (bit for bit) == oracle
     rng = np.random.RandomState(1000 + seed)
@@ -812,7 +812,7 @@ def test_random_configurations(seed):
     dns, bb = [(32, 28), (128, 28), (64, 30), (32, 30)][rng.randint(4)]
     pb = int(rng.randint(0, 4))
     B = int([3, 17, 60, 500][rng.randint(4)])
-    dim = int([8, 33, 64, 100, 130, 256][rng.randint(6)])
+    dim = int(dims[rng.randint(6)])
     metric = ["l2", "dot"][rng.randint(2)]
     k = int([1, 5, 10, 33][rng.randint(4)])
     n, nq = int(rng.randint(1500, 6000)), int(rng.randint(5, 120))
@@ -844,7 +844,7 @@ def test_random_configurations(seed):
     fi, fs = fast.query_topk(pick, Q, steps=steps, k=k)
     if kind == "plain":
         assert fast.stats()["last_path"] == 1
-    if kind == "integers" and metric == "l2" and fast.stats()["last_path"] == 1:
+    if kind == "integers" and metric == "l2" and dim <= 256 and fast.stats()["last_path"] == 1:
         assert fast.stats()["last_scan_int8"] == 1
     si, ss = slow.query_topk(pick, Q, steps=steps, k=k)
     assert np.array_equal(fi, si) and np.array_equal(fs, ss, equal_nan=True)
@@ -852,6 +852,14 @@ def test_random_configurations(seed):
     assert_same_sets(fast.query_batch(pick, Q, steps=steps), (off, ids))
     want = orc.topk(Q64, off, ids, k=k, metric=metric)
     assert_topk_equal(fi, fs, want[0], want[1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(100, 118))
+def test_random_configurations_long_rows(seed):
+    # the same draw over rows of 300 to 1000 dimensions: the scan's forms of 16, 24 and 32 steps (one wave per SIMD with
+    # the chunk's query rows staged in LDS; 16-row tiles beyond 768 dimensions)
+    test_random_configurations(seed, dims=(300, 400, 512, 640, 768, 1000))
 
 
 @pytest.mark.parametrize("groups", [2, 3, 8])
