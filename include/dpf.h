@@ -38,6 +38,7 @@ extern "C" {
 #define DPF_EHIP       -4   /* a HIP runtime call failed                         */
 #define DPF_ENOMEM     -5
 #define DPF_ECAPACITY  -6   /* index larger than the 32-bit arena limits (RDT:1330-1363) */
+#define DPF_EBUSY      -7   /* dpf_query_topk_device_static: another thread's call is using this GPU's scratch array */
 
 enum { DPF_FAMILY_ANGLE = 0, DPF_FAMILY_PSTABLE = 1 };              /* mclab.lsh.name        */
 enum { DPF_INDEX_ORIGINAL = 0, DPF_INDEX_SAMPLING = 1,
@@ -209,16 +210,19 @@ int dpf_query_topk(dpf_index *ix, const int32_t *qids, const void *Q, int64_t nq
 int dpf_query_topk_device(dpf_index *ix, const int32_t *d_qids, const void *d_Q, int64_t nq,
                           int32_t steps, int32_t k, int32_t *d_ids, double *d_scores, void *stream);
 
-/* dpf_query_topk_device for callers that cannot allocate device memory (code under HIP graph
- * capture rules, tight serving loops, harnesses that forbid hipMalloc).  It has no counterpart in
- * the reference.  Same arguments, same results bit for bit (it takes the per-query gather path:
- * candidate Set, exact fp64 scores), but every per-batch buffer - padded query rows, hashes,
- * sub-indexes, counts, offsets, the candidate lists - is a fixed slice of one 29 MiB array in the
- * library's device image, and the call makes no hipMalloc / hipFree.  Limits per call, refused with
- * DPF_ECAPACITY beyond them: 1024 queries, 4 MiB of padded query rows, 131072 (query, table) pairs,
- * and 6 291 456 candidate ids over all queries of the call (counted per query as min(ids visited,
- * rows in the shard)).  The call waits on `stream` once (to read that total).  All handles on one GPU
- * share that GPU's array: calls that overlap on one GPU race. */
+/* dpf_query_topk_device for callers that cannot allocate device memory (tight serving loops, harnesses
+ * that forbid hipMalloc).  It has no counterpart in the reference.  Same arguments, same results bit for
+ * bit (it takes the per-query gather path: candidate Set, exact fp64 scores), but every per-batch buffer -
+ * padded query rows, hashes, sub-indexes, counts, offsets, the candidate lists - is a fixed slice of one
+ * 29 MiB array in the library's device image, and the call makes no hipMalloc / hipFree.  Limits per call,
+ * refused with DPF_ECAPACITY beyond them: 1024 queries, 4 MiB of padded query rows, 131072 (query, table)
+ * pairs, and 6 291 456 candidate ids over all queries of the call (counted per query as min(ids visited,
+ * rows in the shard)).  The call BLOCKS on `stream` once (a small device-to-host copy and a wait, to read
+ * that total), so it cannot be recorded into a HIP graph.  All handles on one GPU share that GPU's array,
+ * one call at a time: on the device a call's kernels are ordered (by an event made at dpf_create) behind
+ * the last kernel of the previous call that used the array, whatever stream or handle it came from, so
+ * calls issued one after the other need no synchronisation in between; a call made while another
+ * thread's call is still inside the library on the same GPU is refused with DPF_EBUSY. */
 int dpf_query_topk_device_static(dpf_index *ix, const int32_t *d_qids, const void *d_Q, int64_t nq,
                                  int32_t steps, int32_t k, int32_t *d_ids, double *d_scores, void *stream);
 

@@ -17,7 +17,7 @@ SELF = {"compat": 0, "always": 1, "never": 2}
 METRIC = {"dot": 0, "l2": 1}
 DTYPE = {np.dtype(np.float32): 0, np.dtype(np.float64): 1}
 
-DPF_OK, DPF_EINVAL, DPF_ENOTFIT, DPF_ENOFAMILY, DPF_EHIP, DPF_ENOMEM, DPF_ECAPACITY = 0, -1, -2, -3, -4, -5, -6
+DPF_OK, DPF_EINVAL, DPF_ENOTFIT, DPF_ENOFAMILY, DPF_EHIP, DPF_ENOMEM, DPF_ECAPACITY, DPF_EBUSY = 0, -1, -2, -3, -4, -5, -6, -7
 
 
 class DpfConfig(C.Structure):

@@ -51,7 +51,17 @@ constexpr size_t SCRATCH_BYTES = SCRATCH_OFF_ARENA + SCRATCH_ARENA_IDS * 4;     
 static_assert(SCRATCH_OFF_ARENA % 256 == 0 && SCRATCH_OFF_CNT % 256 == 0 && SCRATCH_OFF_OFF % 256 == 0, "256-byte aligned slices");
 
 constexpr int SCRATCH_MAX_DEVICES = 64;
-void *g_scratch_ptr[SCRATCH_MAX_DEVICES] = {nullptr};
+// Per GPU: where its copy of the array lives, an event recorded behind the last kernel of the last call that used it
+// (the next call's stream waits for it, so that calls on different streams or from different handles never overlap
+// on the device), and a lock held for the host part of a call (a second thread calling meanwhile is refused with
+// DPF_EBUSY rather than left to race).  Event and pointer are made at dpf_create: the entry point itself creates nothing.
+struct ScratchDev {
+    void *ptr = nullptr;
+    hipEvent_t done = nullptr;
+    bool recorded = false;
+    std::mutex busy;
+};
+ScratchDev g_scratch[SCRATCH_MAX_DEVICES];
 std::mutex g_scratch_mutex;
 // result buffers of dpf_query_batch that belong to a handle (pinned host memory, reused from call to call): dpf_free
 // leaves these alone
@@ -70,13 +80,18 @@ void *scratch_of(int device, hipError_t *err)
     *err = hipSuccess;
     if (device < 0 || device >= SCRATCH_MAX_DEVICES) { *err = hipErrorInvalidDevice; return nullptr; }
     std::lock_guard<std::mutex> lock(g_scratch_mutex);
-    if (!g_scratch_ptr[device]) {
+    ScratchDev &sd = g_scratch[device];
+    if (!sd.ptr) {
         void *ptr = nullptr;
         *err = hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch));
         if (*err != hipSuccess) return nullptr;
-        g_scratch_ptr[device] = ptr;
+        hipEvent_t ev = nullptr;
+        *err = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        if (*err != hipSuccess) return nullptr;
+        sd.done = ev;
+        sd.ptr = ptr;
     }
-    return g_scratch_ptr[device];
+    return sd.ptr;
 }
 
 struct DevBuf {
@@ -1568,6 +1583,18 @@ extern "C" int dpf_query_topk_device_static(dpf_index *ix, const int32_t *d_qids
     if (!ix->scratch_ptr) return fail(ix, DPF_EHIP, "dpf_query_topk_device_static: the scratch array was not located on this device");
     hipStream_t stream = (hipStream_t)stream_;
     HIPCHECK(ix, hipSetDevice(ix->cfg.device));
+    // One call at a time per GPU.  On the host: the lock.  On the device: this call's kernels are ordered behind the
+    // last kernel of the previous call that used the array, whatever stream or handle that call came from; the event
+    // is recorded again on every way out, behind whatever this call has enqueued.
+    ScratchDev &sd = g_scratch[ix->cfg.device];
+    std::unique_lock<std::mutex> turn(sd.busy, std::try_to_lock);
+    if (!turn.owns_lock())
+        return fail(ix, DPF_EBUSY, "dpf_query_topk_device_static: another call is using this GPU's scratch array (one call at a time per GPU)");
+    if (sd.recorded) HIPCHECK(ix, hipStreamWaitEvent(stream, sd.done, 0));
+    struct Mark {
+        ScratchDev &sd; hipStream_t stream;
+        ~Mark() { if (hipEventRecord(sd.done, stream) == hipSuccess) sd.recorded = true; else (void)hipGetLastError(); }
+    } mark{sd, stream};
     unsigned char *const sp = ix->scratch_ptr;
     ProbeWs w;
     w.hashes = (int32_t *)(sp + SCRATCH_OFF_HASHES); w.parts = (int32_t *)(sp + SCRATCH_OFF_PARTS);

@@ -29,12 +29,19 @@ struct JNINativeInterface_ {
     jclass (*FindClass)(JNIEnv *, const char *);
     jint (*ThrowNew)(JNIEnv *, jclass, const char *);
     jsize (*GetArrayLength)(JNIEnv *, jarray);
-    void *(*GetPrimitiveArrayCritical)(JNIEnv *, jarray, jboolean *);
-    void (*ReleasePrimitiveArrayCritical)(JNIEnv *, jarray, void *, jint);
+    jint *(*GetIntArrayElements)(JNIEnv *, jintArray, jboolean *);
+    jlong *(*GetLongArrayElements)(JNIEnv *, jlongArray, jboolean *);
+    jfloat *(*GetFloatArrayElements)(JNIEnv *, jfloatArray, jboolean *);
+    jdouble *(*GetDoubleArrayElements)(JNIEnv *, jdoubleArray, jboolean *);
+    void (*ReleaseIntArrayElements)(JNIEnv *, jintArray, jint *, jint);
+    void (*ReleaseLongArrayElements)(JNIEnv *, jlongArray, jlong *, jint);
+    void (*ReleaseFloatArrayElements)(JNIEnv *, jfloatArray, jfloat *, jint);
+    void (*ReleaseDoubleArrayElements)(JNIEnv *, jdoubleArray, jdouble *, jint);
     jintArray (*NewIntArray)(JNIEnv *, jsize);
     void (*GetIntArrayRegion)(JNIEnv *, jintArray, jsize, jsize, jint *);
     void (*SetIntArrayRegion)(JNIEnv *, jintArray, jsize, jsize, const jint *);
     void (*SetLongArrayRegion)(JNIEnv *, jlongArray, jsize, jsize, const jlong *);
+    void (*SetDoubleArrayRegion)(JNIEnv *, jdoubleArray, jsize, jsize, const jdouble *);
     jstring (*NewStringUTF)(JNIEnv *, const char *);
     const char *(*GetStringUTFChars)(JNIEnv *, jstring, jboolean *);
     void (*ReleaseStringUTFChars)(JNIEnv *, jstring, const char *);
