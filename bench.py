@@ -102,6 +102,17 @@ def ground_truth_l2(torch, dX, dQ, k, chunk=500):
     return torch.cat(out).cpu().numpy()
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(params, X, Q, pick, steps, k, metric, target_s=12.0):
     """The CPU restatement of the reference path, reference threading (5 threads, each
     owning a table range, DensevectorRDFInit.scala:344-350; single-threaded rerank,
@@ -134,6 +145,9 @@ def cpu_baseline(params, X, Q, pick, steps, k, metric, target_s=12.0):
                      "C restatement of the reference path (oracle/), reference threading: 5 query threads over "
                      "table ranges, single-threaded rerank" % (m, steps, k),
            "all_cores_value": m / dt_all, "all_cores": all_threads, "index_build_s": round(fit_s, 2),
+           "host_cores": cores, "cpu_model": cpu_model(),
+           "threads_note": "value: 5 threads (the reference's queryThreadNum); all_cores_value: min(16, host_cores) threads - "
+                           "a one-GPU box is given 16 of the host's cores",
            "misflag_events": orc.misflag_events}
     orc.close()
     return res, last["ids"], last["scores"]
@@ -180,6 +194,90 @@ def roofline_of(ix, run_batch, nbatches, repeats, n, nq, world, workload_name, s
     return out, st
 
 
+OOS_RECIPE = {"c2": "clustered", "c3": "clustered", "c4": "sift", "c5": "unit"}
+
+
+def out_of_sample_record(torch, ix, args, X, nq, k, steps, dev, d_ids, d_sc):
+    """The timed index queried with batches that are NOT noisy copies of base rows: fresh draws from the distribution
+    the base was drawn from.  The first radii of such queries are wider, so more rows pass the filter."""
+    from similaritysearchbyrdf_amd import synthetic
+    nb = max(1, args.batches)
+    batches = []
+    for b in range(nb):
+        qb, ib = synthetic.fresh_queries(OOS_RECIPE[args.workload], X, nq, seed=7000 + b)
+        batches.append((torch.from_numpy(qb).to(dev), torch.from_numpy(ib).to(dev)))
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def run(b):
+        ix.query_topk_device(batches[b][1].data_ptr(), batches[b][0].data_ptr(), nq, steps, k, d_ids.data_ptr(), d_sc.data_ptr(), stream)
+    for b in range(nb + 1):
+        run(b % nb)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = max(nb, min(args.steps, 12))
+    for i in range(reps):
+        run(i % nb)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    run(0)
+    torch.cuda.synchronize()
+    st = ix.stats()
+    rec = {"queries": "fresh draws from the base's distribution (%s), ids -1: no query is a stored row" % OOS_RECIPE[args.workload],
+           "ms_per_step": dt * 1e3, "queries_per_s": nq / dt,
+           "forwarded_to_exact_rerank_per_query": st["last_forwarded"] / nq,
+           "bucket_incidences_per_query": st["last_pairs"] / nq, "ids_visited_per_query": st["last_raw_candidates"] / nq,
+           "overflowed_queries_last_batch": st["last_overflowed"], "rerank_path": "bucket-major" if st["last_path"] == 1 else "gather"}
+    if not args.no_recall and args.metric == "l2":
+        ids = d_ids.cpu().numpy()
+        dX = torch.from_numpy(X).to(dev)
+        gt = ground_truth_l2(torch, dX, batches[0][0], k)
+        del dX
+        rec["recall_at_%d" % k] = sum(len(np.intersect1d(ids[q][ids[q] >= 0], gt[q])) for q in range(nq)) / float(nq * k)
+    return rec
+
+
+def c1_record(args, k):
+    """BASELINE configs[0], the reference's README "simple test" (README.md:32-43) at its stated size: 20 000 100-d
+    vectors (GloVe is not available offline: the c2 / c3 generator), the default forest (10 x 3 trees, 3 partition bits,
+    bucket overflow 500), two queries with components uniform in [0, 1), ids 0 and 1, NewMultiThreadQueryBatch with
+    0 steps.  Candidate Sets and top-k of both queries against the CPU oracle."""
+    from oracle import oracle as O
+    from similaritysearchbyrdf_amd import synthetic
+    from similaritysearchbyrdf_amd._lib import DpfIndex
+    params = synthetic.make_family(100, table_num=10, permutation_num=3, chain_length=32, family="angle",
+                                   family_size=100, partition_bits=3, orthogonal=True)
+    params.update(bucket_overflow=500, dir_node_size=32, bucket_bits=28, exclude_self="compat")
+    X, _, _ = synthetic.make_clustered(20_000, 100, 2)
+    Q, _ = synthetic.fresh_queries("uniform", X, 2, seed=5)
+    qids = np.array([0, 1], dtype=np.int32)
+    gi = DpfIndex(params, metric="dot", top_k=k, dtype=np.float32, device=0)
+    t0 = time.perf_counter()
+    gi.fit(X)
+    fit_s = time.perf_counter() - t0
+    orc = O.OracleIndex(params)
+    orc.fit(X.astype(np.float64))
+    rec = {"workload": "c1: 20000 x 100-d, 30 trees, 2 uniform-[0,1) queries (README simple test)", "fit_seconds": round(fit_s, 4), "steps": {}}
+    same_all = True
+    for st_ in (0, 1, 2, 3):
+        off, ids = gi.query_batch(qids, Q, steps=st_)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            gi.query_batch(qids, Q, steps=st_)
+        ms = (time.perf_counter() - t0) / 5 * 1e3
+        woff, wids = orc.query_batch(qids, Q.astype(np.float64), steps=st_)
+        same_sets = bool(np.array_equal(off, woff) and np.array_equal(ids, wids))
+        ti, ts = gi.query_topk(qids, Q, steps=st_, k=k)
+        wi, ws = orc.topk(Q.astype(np.float64), woff, wids, k=k, metric="dot")
+        same_topk = bool(np.array_equal(ti, wi))
+        same_all = same_all and same_sets and same_topk
+        rec["steps"][str(st_)] = {"set_sizes": [int(off[1] - off[0]), int(off[2] - off[1])], "same_sets_as_oracle": same_sets,
+                                  "same_top%d_as_oracle" % k: same_topk, "query_batch_ms": ms}
+    rec["oracle_check"] = same_all
+    orc.close()
+    gi.close()
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -196,6 +294,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-recall", action="store_true")
     ap.add_argument("--no-host-to-host", action="store_true")
+    ap.add_argument("--no-out-of-sample", action="store_true",
+                    help="skip the record of the same index queried with fresh draws from the base's distribution")
     ap.add_argument("--no-gather-check", action="store_true",
                     help="skip the untimed run of the same batch through the per-query gather rerank (its candidate lists need "
                          "4 bytes per visited id: too much at 10M base / 100k queries)")
@@ -303,17 +403,35 @@ def main():
     # the query ids, the batch, D2H of ids and scores)
     h2h = None
     if world == 1 and not args.no_host_to_host:
-        for b in range(min(2, nb)):
-            ix.query_topk(host_batches[b][1], host_batches[b][0], steps=steps, k=k)
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            qb, pb_ = host_batches[i % nb]
-            ix.query_topk(pb_, qb, steps=steps, k=k)
-        dth = time.perf_counter() - t0
+        from similaritysearchbyrdf_amd._lib import pinned_array
+
+        def timed_h2h(batches, out):
+            for b in range(min(2, nb)):
+                ix.query_topk(batches[b][1], batches[b][0], steps=steps, k=k, out=out)
+            t0_ = time.perf_counter()
+            for i in range(args.steps):
+                qb, pb_ = batches[i % nb]
+                ix.query_topk(pb_, qb, steps=steps, k=k, out=out)
+            return time.perf_counter() - t0_
+
+        dth = timed_h2h(host_batches, None)
+        # the same from / into pinned host memory (dpf_host_alloc): the copy engines move it from where it lies
+        pin_batches = []
+        for qb, pb_ in host_batches:
+            pq, pp = pinned_array(qb.shape, qb.dtype), pinned_array(pb_.shape, np.int32)
+            pq[...] = qb
+            pp[...] = pb_
+            pin_batches.append((pq, pp))
+        pin_out = (pinned_array((nq, k), np.int32), pinned_array((nq, k), np.float64))
+        dtp = timed_h2h(pin_batches, pin_out)
+        del pin_batches, pin_out
         h2h = {"value": nq * args.steps / dth, "ms_per_step": dth / args.steps * 1e3,
                "h2d_d2h_and_sync_ms_per_step": (dth - dt) / args.steps * 1e3,
                "bytes_per_step": {"h2d": int(nq * X.shape[1] * 4 + nq * 4), "d2h": int(nq * k * 12)},
-               "host_memory": "pageable (numpy arrays handed to dpf_query_topk)"}
+               "host_memory": "pageable (numpy arrays handed to dpf_query_topk; staged through the handle's pinned area in 1 MiB pieces)",
+               "pinned": {"value": nq * args.steps / dtp, "ms_per_step": dtp / args.steps * 1e3,
+                          "h2d_d2h_and_sync_ms_per_step": (dtp - dt) / args.steps * 1e3,
+                          "host_memory": "pinned (dpf_host_alloc) query matrix, ids and result arrays: asynchronous copies, no staging"}}
 
     # Two batches in flight: a second handle over the same base, each handle driven by its own host thread on its own
     # stream, the same rotation of batches split between them.  What a serving loop gains when the probe / threshold /
@@ -460,6 +578,15 @@ def main():
         li.close()
         del Xl, lb
 
+    oos = None
+    if rank == 0 and world == 1 and not args.no_out_of_sample:
+        oos = out_of_sample_record(torch, ix, args, X, nq, k, steps, dev, d_ids, d_sc)
+        run_batch(0)
+        fence()
+    c1 = None
+    if rank == 0 and world == 1 and args.workload == "c3" and not args.no_cpu_baseline:
+        c1 = c1_record(args, k)
+
     if rank == 0:
         out = {
             "metric": "queries/sec @ recall@10, GloVe-100d 1M base / 10k query batch",
@@ -492,8 +619,13 @@ def main():
                        "misflag_events": st["misflag_events"], "short_hash_events": st["short_hash_events"]},
             "roofline": roofline,
         }
+        out["value_device_resident"] = out["value"]
+        out["value_note"] = ("value = query matrix and result arrays resident in HBM when the timed region starts; "
+                             "value_host_to_host = host query matrix in, host ids + scores out (pageable memory), "
+                             "value_host_to_host_pinned = the same through pinned host memory")
         if h2h is not None:
             out["value_host_to_host"] = h2h["value"]
+            out["value_host_to_host_pinned"] = h2h["pinned"]["value"]
             out["host_to_host"] = h2h
         if two is not None:
             out["value_two_in_flight"] = two["value"]
@@ -504,6 +636,10 @@ def main():
             out["sampled_gather_check"] = sampled
         if large is not None:
             out["roofline_large_table"] = large
+        if oos is not None:
+            out["out_of_sample"] = oos
+        if c1 is not None:
+            out["c1"] = c1
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], o_ids, o_sc = cpu_baseline(params, X, Q, pick, steps, k, args.metric)
             m = o_ids.shape[0]

@@ -24,6 +24,7 @@
 #ifndef DPF_H
 #define DPF_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -194,9 +195,15 @@ void dpf_free(void *p);
 
 /* The query + rerank of DensevectorRDFInit.topKAndPrecisionScore (Dense:472-507)
  * without the ground-truth scoring: ids[nq][k] (-1 padded) and scores[nq][k]
- * (NaN padded), best first.  Host pointers. */
+ * (NaN padded), best first.  Host pointers.  Arguments and results in pinned host memory (dpf_host_alloc,
+ * hipHostMalloc, hipHostRegister) are copied by the device's copy engines from / to where they lie; ordinary
+ * (pageable) memory goes through a pinned staging area of the handle, piece by piece. */
 int dpf_query_topk(dpf_index *ix, const int32_t *qids, const void *Q, int64_t nq, int32_t steps,
                    int32_t k, int32_t *ids, double *scores);
+/* Pinned host memory for the host-pointer entry points (no counterpart in the reference, whose arrays live on
+ * the JVM heap; a JVM caller wraps the block in a direct ByteBuffer).  dpf_host_free releases it. */
+int dpf_host_alloc(size_t bytes, void **out);
+void dpf_host_free(void *p);
 
 /* Same, every buffer already in HBM, the kernels enqueued on `stream` (a hipStream_t, NULL =
  * the default stream).  The call BLOCKS: it waits on `stream` once per batch (twice on a handle's

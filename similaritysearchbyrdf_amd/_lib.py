@@ -49,7 +49,7 @@ EXPORTS = (
     "dpf_query_topk", "dpf_query_topk_device", "dpf_rerank", "dpf_merge_topk_device", "dpf_merge_topk_packed_device",
     "dpf_subindex_distribution", "dpf_get_stats", "dpf_last_rerank_profile", "dpf_set_profiling",
     "dpf_save", "dpf_load", "dpf_get_config", "dpf_snapshot_sizes", "dpf_snapshot_copy", "dpf_set_option", "dpf_query_topk_device_static",
-    "dpf_load_shard", "dpf_set_probe_mode",
+    "dpf_load_shard", "dpf_set_probe_mode", "dpf_host_alloc", "dpf_host_free",
 )
 
 # dpf_set_option keys (include/dpf.h)
@@ -131,8 +131,43 @@ def lib():
     L.dpf_snapshot_copy.argtypes = [vp, vp, vp, vp, vp]
     L.dpf_get_config.restype = C.c_int
     L.dpf_get_config.argtypes = [vp, C.POINTER(DpfConfig)]
+    L.dpf_host_alloc.restype = C.c_int
+    L.dpf_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
+    L.dpf_host_free.restype = None
+    L.dpf_host_free.argtypes = [vp]
     _lib = L
     return L
+
+
+class _PinnedBlock:
+    """Owner of one dpf_host_alloc block; numpy arrays made over it keep it alive through their .base chain."""
+
+    def __init__(self, nbytes):
+        self.L_ = lib()
+        self.ptr = C.c_void_p()
+        rc = self.L_.dpf_host_alloc(max(int(nbytes), 1), C.byref(self.ptr))
+        if rc != 0:
+            raise DpfError(rc, self.L_.dpf_last_error(None).decode())
+        self.nbytes = max(int(nbytes), 1)
+
+    def __del__(self):
+        try:
+            if self.ptr.value:
+                self.L_.dpf_host_free(self.ptr)
+                self.ptr = C.c_void_p()
+        except Exception:
+            pass
+
+
+def pinned_array(shape, dtype):
+    """A numpy array in pinned host memory (dpf_host_alloc): the host-pointer entry points copy it by DMA from / to
+    where it lies instead of staging it."""
+    dtype = np.dtype(dtype)
+    n = int(np.prod(shape))
+    block = _PinnedBlock(n * dtype.itemsize)
+    buf = (C.c_char * block.nbytes).from_address(block.ptr.value)
+    buf._owner = block                         # a from_address buffer does not own its memory: the array keeps buf, buf the block
+    return np.frombuffer(buf, dtype=dtype, count=n).reshape(shape)
 
 
 def _dp(a):
@@ -270,13 +305,20 @@ class DpfIndex:
         self.L_.dpf_free(pids)
         return offsets, ids
 
-    def query_topk(self, qids, Q, steps=0, k=None):
+    def query_topk(self, qids, Q, steps=0, k=None, out=None):
+        """out = (ids [nq, k] int32, scores [nq, k] float64) to have the results written into given arrays
+        (pinned ones, pinned_array(), are filled by DMA)."""
         Q = self._rows(Q)
         nq = Q.shape[0]
         k = k or self.top_k
         qids = _i32(qids)
-        ids = np.empty((nq, k), dtype=np.int32)
-        sc = np.empty((nq, k), dtype=np.float64)
+        if out is not None:
+            ids, sc = out
+            assert ids.dtype == np.int32 and sc.dtype == np.float64 and ids.shape == (nq, k) and sc.shape == (nq, k)
+            assert ids.flags.c_contiguous and sc.flags.c_contiguous
+        else:
+            ids = np.empty((nq, k), dtype=np.int32)
+            sc = np.empty((nq, k), dtype=np.float64)
         self._check(self.L_.dpf_query_topk(self.h, _ip(qids), Q.ctypes.data, nq, steps, k, _ip(ids), _dp(sc)))
         return ids, sc
 

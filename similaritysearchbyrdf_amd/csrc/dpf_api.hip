@@ -128,6 +128,30 @@ struct DevBuf {
     template <typename T> T *as() const { return (T *)p; }
 };
 
+// pinned host memory, grown on demand
+struct PinBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+        const size_t want = bytes + bytes / 4 + 4096;
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
+// true for memory the device can copy from / to directly (hipHostMalloc, hipHostRegister, dpf_host_alloc)
+bool host_pinned(const void *p)
+{
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+}
+
 }  // namespace
 
 struct dpf_index {
@@ -193,6 +217,7 @@ struct dpf_index {
     DevBuf ws_qpad, ws_hashes, ws_parts, ws_raw, ws_bound, ws_off, ws_cnt, ws_arena, ws_misc;
     DevBuf ws_hq, ws_hqids, ws_hids, ws_hscores;     // device copies for the host-pointer entry points
     DevBuf ws_stage;                                  // fit staging
+    PinBuf h_stage;                                   // host-pointer entry points: pinned staging of pageable arguments / results
     DevBuf ws_lq_off, ws_lq_cursor, ws_leaf_queries, ws_seed_cand, ws_seed_cnt, ws_seed_ids,
         ws_seed_scores, ws_emit, ws_emit_cnt, ws_flag, ws_tau;
     hipEvent_t ev_scan[6]{};                          // begin and end of up to three passes of the scan
@@ -354,6 +379,7 @@ extern "C" void dpf_destroy(dpf_index *ix)
     if (ix->d_proj_counters) (void)hipFree(ix->d_proj_counters);
     { DevBuf *pb[] = {&ix->d_fn_norm, &ix->ws_proj_codes, &ix->ws_proj_norm, &ix->ws_proj_flag, &ix->ws_proj_rows}; for (DevBuf *b : pb) b->release(); }
     if (ix->pinned) (void)hipHostFree(ix->pinned);
+    ix->h_stage.release();
     if (ix->h_sets) {
         {
             std::lock_guard<std::mutex> lock(g_results_mutex);
@@ -508,7 +534,7 @@ static int hash_rows(dpf_index *ix, const void *X, int64_t stride, int64_t n, in
     ws.flag_rows = ix->ws_proj_rows.as<int32_t>();
     ws.flag_count = (uint32_t *)ix->d_proj_counters;
     ws.flag_total = (unsigned long long *)(ix->d_proj_counters + 8);
-    launch_hash_mfma(ix->cfg.dtype, X, stride, n, ix->hp, ws, hashes, parts, stream);
+    HIPCHECK(ix, launch_hash_mfma(ix->cfg.dtype, X, stride, n, ix->hp, ws, hashes, parts, stream));
     return DPF_OK;
 }
 
@@ -1290,10 +1316,17 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     // handle's side stream, beside the radii.
     const bool fork = carried && ix->opt_side_stream && !ix->profiling && ix->side_stream != nullptr;
     hipStream_t ls = stream;
+    // (an early return between the fork and the join - a failed call, a workspace that cannot grow - must not leave
+    // the side stream's kernels writing the handle's buffers behind the caller's back: the guard waits them out)
+    struct SideGuard {
+        hipStream_t side = nullptr;
+        ~SideGuard() { if (side) { (void)hipStreamSynchronize(side); (void)hipGetLastError(); } }
+    } side_guard;
     if (fork) {
         HIPCHECK(ix, hipEventRecord(ix->ev_fork, stream));
         HIPCHECK(ix, hipStreamWaitEvent(ix->side_stream, ix->ev_fork, 0));
         ls = ix->side_stream;
+        side_guard.side = ix->side_stream;
     }
     launch_bucket_scans(lq_cnt_of(ix), ix->d_leaf_tile0.as<uint32_t>(), nl, ix->ws_lq_off.as<int64_t>(),
                         ix->ws_unit_off.as<int64_t>(), d_totals, carried, cap_pairs, cap_units, flags,
@@ -1381,7 +1414,10 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
                           (float4 *)ix->ws_qc8.p, d_qids, i8_gate, stream);
     }
     HIPCHECK(ix, ix->ws_emit_v.ensure((size_t)nq * EMIT_CAP * 4));
-    if (fork) HIPCHECK(ix, hipStreamWaitEvent(stream, ix->ev_join, 0));     // the scan needs both chains
+    if (fork) {                                                             // the scan needs both chains
+        HIPCHECK(ix, hipStreamWaitEvent(stream, ix->ev_join, 0));
+        side_guard.side = nullptr;
+    }
     LeafScanParams lp;
     lp.ids = ix->d_ids.as<int32_t>();
     lp.leaf_queries = ix->ws_leaf_queries.as<int32_t>();
@@ -1623,6 +1659,26 @@ extern "C" int dpf_query_topk_device_static(dpf_index *ix, const int32_t *d_qids
     return DPF_OK;
 }
 
+// Host rows -> device, enqueued on `stream`.  Pinned memory is copied from where it lies; pageable memory goes through
+// the handle's pinned staging area (at byte `at`) in 1 MiB pieces, so that the transfer of one piece runs while the
+// next is being staged.  The staging area is reused only after the call's final stream wait.
+static int stage_to_device(dpf_index *ix, void *dst, const void *src, size_t bytes, size_t at, hipStream_t stream)
+{
+    if (bytes == 0) return DPF_OK;
+    if (host_pinned(src)) {
+        HIPCHECK(ix, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream));
+        return DPF_OK;
+    }
+    const size_t piece = (size_t)1 << 20;
+    char *stage = (char *)ix->h_stage.p + at;
+    for (size_t o = 0; o < bytes; o += piece) {
+        const size_t len = std::min(piece, bytes - o);
+        memcpy(stage + o, (const char *)src + o, len);
+        HIPCHECK(ix, hipMemcpyAsync((char *)dst + o, stage + o, len, hipMemcpyHostToDevice, stream));
+    }
+    return DPF_OK;
+}
+
 extern "C" int dpf_query_topk(dpf_index *ix, const int32_t *qids, const void *Q, int64_t nq, int32_t steps,
                               int32_t k, int32_t *ids, double *scores)
 {
@@ -1632,22 +1688,56 @@ extern "C" int dpf_query_topk(dpf_index *ix, const int32_t *qids, const void *Q,
     if (nq < 0 || (nq > 0 && (!Q || !ids || !scores)) || k < 1 || k > 64) return fail(ix, DPF_EINVAL, "dpf_query_topk: bad arguments");
     if (nq == 0) return DPF_OK;
     HIPCHECK(ix, hipSetDevice(ix->cfg.device));
-    const size_t qbytes = (size_t)nq * ix->cfg.dim * ix->elem;
+    hipStream_t stream = nullptr;
+    const size_t qbytes = (size_t)nq * ix->cfg.dim * ix->elem, idbytes = (size_t)nq * 4;
+    const size_t obytes_i = (size_t)nq * k * 4, obytes_s = (size_t)nq * k * 8;
+    // staging layout: query rows, query ids, result scores, result ids (each part 256-byte aligned)
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t at_ids = up(qbytes), at_os = at_ids + up(idbytes), at_oi = at_os + up(obytes_s);
+    HIPCHECK(ix, ix->h_stage.ensure(at_oi + up(obytes_i)));
     HIPCHECK(ix, ix->ws_hq.ensure(qbytes));
-    HIPCHECK(ix, ix->ws_hids.ensure((size_t)nq * k * 4));
-    HIPCHECK(ix, ix->ws_hscores.ensure((size_t)nq * k * 8));
-    HIPCHECK(ix, hipMemcpy(ix->ws_hq.p, Q, qbytes, hipMemcpyHostToDevice));
+    HIPCHECK(ix, ix->ws_hids.ensure(obytes_i));
+    HIPCHECK(ix, ix->ws_hscores.ensure(obytes_s));
+    if ((rc = stage_to_device(ix, ix->ws_hq.p, Q, qbytes, 0, stream)) != DPF_OK) return rc;
     const int32_t *dq = nullptr;
     if (qids) {
-        HIPCHECK(ix, ix->ws_hqids.ensure((size_t)nq * 4));
-        HIPCHECK(ix, hipMemcpy(ix->ws_hqids.p, qids, (size_t)nq * 4, hipMemcpyHostToDevice));
+        HIPCHECK(ix, ix->ws_hqids.ensure(idbytes));
+        if ((rc = stage_to_device(ix, ix->ws_hqids.p, qids, idbytes, at_ids, stream)) != DPF_OK) return rc;
         dq = ix->ws_hqids.as<int32_t>();
     }
-    rc = dpf_query_topk_device(ix, dq, ix->ws_hq.p, nq, steps, k, ix->ws_hids.as<int32_t>(), ix->ws_hscores.as<double>(), nullptr);
+    rc = dpf_query_topk_device(ix, dq, ix->ws_hq.p, nq, steps, k, ix->ws_hids.as<int32_t>(), ix->ws_hscores.as<double>(), stream);
     if (rc != DPF_OK) return rc;
-    HIPCHECK(ix, hipMemcpy(ids, ix->ws_hids.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost));
-    HIPCHECK(ix, hipMemcpy(scores, ix->ws_hscores.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost));
+    // results: straight into pinned caller memory, else into the staging area and from there with the CPU
+    const bool pin_i = host_pinned(ids), pin_s = host_pinned(scores);
+    void *ti = pin_i ? (void *)ids : (void *)((char *)ix->h_stage.p + at_oi);
+    void *ts = pin_s ? (void *)scores : (void *)((char *)ix->h_stage.p + at_os);
+    HIPCHECK(ix, hipMemcpyAsync(ti, ix->ws_hids.p, obytes_i, hipMemcpyDeviceToHost, stream));
+    HIPCHECK(ix, hipMemcpyAsync(ts, ix->ws_hscores.p, obytes_s, hipMemcpyDeviceToHost, stream));
+    HIPCHECK(ix, hipStreamSynchronize(stream));
+    if (!pin_i) memcpy(ids, ti, obytes_i);
+    if (!pin_s) memcpy(scores, ts, obytes_s);
     return DPF_OK;
+}
+
+// Pinned host memory for callers of the host-pointer entry points (a JVM wraps it in a direct ByteBuffer): arguments
+// and results that lie in it are moved by the device's copy engines without a staging copy.
+extern "C" int dpf_host_alloc(size_t bytes, void **out)
+{
+    if (!out) return DPF_EINVAL;
+    *out = nullptr;
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        g_create_error = "dpf_host_alloc: hipHostMalloc failed";
+        return DPF_ENOMEM;
+    }
+    *out = p;
+    return DPF_OK;
+}
+
+extern "C" void dpf_host_free(void *p)
+{
+    if (p) (void)hipHostFree(p);
 }
 
 extern "C" int dpf_hash_batch(dpf_index *ix, const void *Q, int64_t nq, int32_t *hashes, int32_t *parts)

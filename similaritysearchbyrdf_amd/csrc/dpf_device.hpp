@@ -147,8 +147,8 @@ struct ProjectWs {
     unsigned long long *flag_total = nullptr;   // running total over all calls (statistics)
 };
 size_t project_codes_bytes(const HashParams &p, int64_t n);
-void launch_hash_mfma(int dtype, const void *X, int64_t x_stride, int64_t n, const HashParams &p, const ProjectWs &ws,
-                      int32_t *hashes, int32_t *parts, hipStream_t stream);
+hipError_t launch_hash_mfma(int dtype, const void *X, int64_t x_stride, int64_t n, const HashParams &p, const ProjectWs &ws,
+                            int32_t *hashes, int32_t *parts, hipStream_t stream);
 void launch_probe(int mode, const ProbeParams &p, int64_t nq, hipStream_t stream);
 void launch_fill_lists(const ProbeParams &p, int64_t nq, hipStream_t stream);
 void launch_seed_sample(const ProbeParams &p, int64_t nq, hipStream_t stream);

@@ -65,8 +65,9 @@ __global__ __launch_bounds__(256) void k_row_norm(const T *__restrict__ X, int64
     if (lane == 0) { out[row] = sqrt(s); row_flag[row] = 0u; }
 }
 
-// The contraction.  Grid: x = function tile (fastest, so that neighbouring workgroups share their vector rows in
-// L2), y = vector tile.  Wave w of the workgroup owns vector rows [32 w, 32 w + 32) of the tile and all 64
+// The contraction.  One-dimensional grid: workgroup = vector tile * function tiles + function tile (the function
+// tile runs fastest, so that neighbouring workgroups share their vector rows in L2; a second grid dimension would
+// cap a call at 65535 vector tiles).  Wave w of the workgroup owns vector rows [32 w, 32 w + 32) of the tile and all 64
 // functions: 2 x 4 accumulator tiles of 16 x 16.
 // v_mfma_f64_16x16x4_f64 operand maps: A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15], one fp64
 // per lane; C/D[i = (lane >> 4) + 4 r][j = lane & 15] in register r of the lane.
@@ -80,9 +81,10 @@ __global__ __launch_bounds__(256, 2) void k_project_mfma(const T *__restrict__ X
     __shared__ double Xs[BM][XS];
     __shared__ double Bs[KC][BS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int f0 = blockIdx.x * BN;
-    const int64_t r0 = (int64_t)blockIdx.y * BM;
     const int dim = p.dim, F = p.F;
+    const unsigned ftiles = (unsigned)((F + BN - 1) / BN);
+    const int f0 = (int)(blockIdx.x % ftiles) * BN;
+    const int64_t r0 = (int64_t)(blockIdx.x / ftiles) * BM;
 
     f64x4 acc[2][4];
 #pragma unroll
@@ -229,16 +231,19 @@ size_t project_codes_bytes(const HashParams &p, int64_t n)
     return (size_t)n * (size_t)p.F * 4;
 }
 
-void launch_hash_mfma(int dtype, const void *X, int64_t x_stride, int64_t n, const HashParams &p, const ProjectWs &ws,
-                      int32_t *hashes, int32_t *parts, hipStream_t stream)
+hipError_t launch_hash_mfma(int dtype, const void *X, int64_t x_stride, int64_t n, const HashParams &p, const ProjectWs &ws,
+                            int32_t *hashes, int32_t *parts, hipStream_t stream)
 {
-    if (n <= 0) return;
+    if (n <= 0) return hipSuccess;
     const int ft16 = (p.F + 15) / 16;
-    (void)hipMemsetAsync(ws.flag_count, 0, sizeof(uint32_t), stream);
+    const int64_t tiles = (int64_t)((p.F + BN - 1) / BN) * ((n + BM - 1) / BM);
+    if (tiles > 0x7fffffffll) return hipErrorInvalidConfiguration;
+    hipError_t e = hipMemsetAsync(ws.flag_count, 0, sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
     const dim3 ngrid((unsigned)((n + 3) / 4)), block(256);
     if (dtype == 0) hipLaunchKernelGGL((k_row_norm<float>), ngrid, block, 0, stream, (const float *)X, x_stride, n, p.dim, ws.row_norm, ws.row_flag);
     else hipLaunchKernelGGL((k_row_norm<double>), ngrid, block, 0, stream, (const double *)X, x_stride, n, p.dim, ws.row_norm, ws.row_flag);
-    const dim3 grid((unsigned)((p.F + BN - 1) / BN), (unsigned)((n + BM - 1) / BM));
+    const dim3 grid((unsigned)tiles);
     uint16_t *bits16 = p.family == 0 ? (uint16_t *)ws.codes : nullptr;
     int32_t *codes = p.family == 0 ? nullptr : (int32_t *)ws.codes;
 #define DPF_PROJECT(T, FAM)                                                                                              \
@@ -252,6 +257,7 @@ void launch_hash_mfma(int dtype, const void *X, int64_t x_stride, int64_t n, con
                        ws.row_flag, hashes, parts);
     // the undecided rows, whole, on the exact kernel
     launch_hash_rows(dtype, X, x_stride, n, p, hashes, parts, ws.flag_rows, ws.flag_count, stream);
+    return hipGetLastError();
 }
 
 }  // namespace dpf

@@ -132,3 +132,65 @@ def more_queries(kind, X, nq, seed):
     else:
         raise ValueError(kind)
     return np.ascontiguousarray(Q, dtype=X.dtype), pick
+
+
+def fresh_queries(kind, X, nq, seed):
+    """Out-of-sample queries: NOT noisy copies of base rows but fresh draws from the distribution the base of that
+    recipe was drawn from ("clustered": the same 1000-centre mixture, "sift": the same 256 centres, "unit": fresh unit
+    Gaussian vectors), or "uniform": components uniform in [0, 1) as in the reference's README test
+    (README.md:37-38).  -> (Q [nq, dim], ids [nq] = -1 .. : none of them is a stored row)."""
+    rng = np.random.default_rng(seed)
+    n, dim = X.shape
+    if kind == "clustered":
+        centres = np.random.default_rng(1234).normal(size=(1000, dim)).astype(np.float32)      # make_clustered's first draw
+        Q = centres[rng.integers(0, 1000, size=nq)] + np.float32(0.3) * rng.standard_normal((nq, dim), dtype=np.float32)
+    elif kind == "sift":
+        centres = np.random.default_rng(99).integers(0, 256, size=(256, dim)).astype(np.float32)   # make_sift_like's first draw
+        Q = np.clip(np.rint(centres[rng.integers(0, 256, size=nq)] + np.float32(12.0) * rng.standard_normal((nq, dim), dtype=np.float32)), 0, 255)
+    elif kind == "unit":
+        q = rng.standard_normal((nq, dim), dtype=np.float32)
+        Q = q / np.linalg.norm(q, axis=1, keepdims=True)
+    elif kind == "uniform":
+        Q = rng.random((nq, dim), dtype=np.float32)
+    else:
+        raise ValueError(kind)
+    return np.ascontiguousarray(Q, dtype=X.dtype), np.full(nq, -1, dtype=np.int32)
+
+
+# Row-addressable recipes: row r depends only on (seed, r // ROW_CHUNK, r % ROW_CHUNK), so a rank can produce any
+# range of a base without producing - or holding - the rows before it.
+ROW_CHUNK = 65536
+
+
+def unit_gaussian_rows(lo, hi, dim, seed=777, dtype=np.float32):
+    """Rows [lo, hi) of a base of unit-normalised N(0, I) vectors (the c5 recipe, chunk-seeded)."""
+    out = np.empty((max(hi - lo, 0), dim), dtype=dtype)
+    r = lo
+    while r < hi:
+        c = r // ROW_CHUNK
+        c0 = c * ROW_CHUNK
+        e = min(hi, c0 + ROW_CHUNK)
+        v = np.random.default_rng([seed, c]).standard_normal((ROW_CHUNK, dim), dtype=np.float32)[r - c0:e - c0]
+        out[r - lo:e - lo] = v / np.linalg.norm(v, axis=1, keepdims=True)
+        r = e
+    return out
+
+
+def unit_gaussian_queries(n, dim, nq, noise=0.05, seed=777, qseed=778, dtype=np.float32):
+    """Queries over the unit_gaussian_rows base: rows picked at random plus N(0, noise^2 / dim) noise per component,
+    normalised again; only the picked rows' chunks are generated.  -> (Q [nq, dim], picked rows)."""
+    rng = np.random.default_rng(qseed)
+    pick = rng.integers(0, n, size=nq)
+    rows = np.empty((nq, dim), dtype=np.float32)
+    order = np.argsort(pick, kind="stable")
+    i = 0
+    while i < nq:
+        c = int(pick[order[i]]) // ROW_CHUNK
+        j = i
+        while j < nq and int(pick[order[j]]) // ROW_CHUNK == c:
+            j += 1
+        chunk = unit_gaussian_rows(c * ROW_CHUNK, min(n, (c + 1) * ROW_CHUNK), dim, seed=seed)
+        rows[order[i:j]] = chunk[pick[order[i:j]] - c * ROW_CHUNK]
+        i = j
+    q = rows + np.float32(noise / np.sqrt(dim)) * rng.standard_normal((nq, dim), dtype=np.float32)
+    return np.ascontiguousarray(q / np.linalg.norm(q, axis=1, keepdims=True), dtype=dtype), pick

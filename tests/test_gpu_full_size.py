@@ -116,3 +116,41 @@ def test_c5_share_768d_unit_gaussian():
     params, X, Q, pick, steps, orc, gpu = _fit_both("c5", 1_250_000, 12_500)
     assert X.shape[1] == 768
     _check_batch(params, X, Q, pick, steps, orc, gpu, sample=96, set_steps=(1,), dot_too=False)
+
+
+def test_c1_readme_simple_test_at_size():
+    # BASELINE configs[0] = the reference's README "simple test" (README.md:32-43) at its stated size: 20 000 100-d
+    # vectors, the default forest (tableNum 10 x permutationNum 3, 3 partition bits, bucket overflow 500), two query
+    # vectors with components uniform in [0, 1) and ids 0 and 1 through NewMultiThreadQueryBatch
+    # (DensevectorRDFInit.scala:335-360; README: 0 steps, here every step count) and the descending-inner-product
+    # top-10 of DensevectorRDFInit.scala:472-507.
+    rec = bench.c1_record(type("A", (), {})(), 10)
+    assert rec["oracle_check"] is True, rec
+    for st_ in ("0", "1", "2", "3"):
+        assert rec["steps"][st_]["same_sets_as_oracle"] and rec["steps"][st_]["same_top10_as_oracle"], rec
+    # more steps only add sub-indexes
+    for q in range(2):
+        sizes = [rec["steps"][str(s)]["set_sizes"][q] for s in range(4)]
+        assert sizes == sorted(sizes), sizes
+    # the same flow through the mirrored objects of the reference (text file, LSHServer globals, Set results)
+    import os
+    import tempfile
+    from similaritysearchbyrdf_amd import synthetic
+    from similaritysearchbyrdf_amd.host import Config, DenseVector, DensevectorRDFInit, LSH, LSHServer
+    X, _, _ = synthetic.make_clustered(20_000, 100, 2)
+    Q, _ = synthetic.fresh_queries("uniform", X, 2, seed=5)
+    from tests.test_host_mirror import conf, _write_dense_file, _oracle_for_mirror
+    c = conf()                                            # the reference's TestSettings defaults: 10 x 3 trees, overflow 500
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "glove.like.20k.DenseVector.txt")
+        _write_dense_file(path, X.astype(np.float64), ids=np.arange(20_000))
+        LSHServer.lshEngine = None
+        LSHServer.isUseDense = True
+        LSHServer.lshEngine = LSH(c)
+        assert DensevectorRDFInit.newMultiThreadFit(path, c) == 20_000
+    results = DensevectorRDFInit.NewMultiThreadQueryBatch([0, 1], [DenseVector(0, Q[0].astype(np.float64)), DenseVector(1, Q[1].astype(np.float64))], 0)
+    orc = _oracle_for_mirror(c, 30, 3, 500)
+    orc.fit(X.astype(np.float64))
+    off, ids = orc.query_batch([0, 1], Q.astype(np.float64), steps=0)
+    assert results == [set(ids[off[i]:off[i + 1]].tolist()) for i in range(2)]
+    DensevectorRDFInit.clearAndClose()
