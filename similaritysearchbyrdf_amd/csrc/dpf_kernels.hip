@@ -367,7 +367,11 @@ __global__ __launch_bounds__(MODE == 1 ? 1024 : 256, MODE == 1 ? 4 : 8) void k_p
                     for (int v = 0; v < 4; v++) {
                         raw_local += le[v] - lb[v];
                         place[v] = 0;
+#if defined(DPF_PROBE_ABLATE) && (DPF_PROBE_ABLATE & 1)
+                        if (p.lq_cnt && le[v] > lb[v] && leaf[v >> 1][v & 1] == 0xfffffff0u) place[v] = atomicAdd(&p.lq_cnt[0], 1u);
+#else
                         if (p.lq_cnt && le[v] > lb[v]) place[v] = atomicAdd(&p.lq_cnt[leaf[v >> 1][v & 1]], 1u);
+#endif
                     }
                     if (p.lq_cnt && p.q_leaves) {
                         // one LDS counter update per lane for all of its buckets
@@ -377,7 +381,11 @@ __global__ __launch_bounds__(MODE == 1 ? 1024 : 256, MODE == 1 ? 4 : 8) void k_p
                         for (int v = 0; v < 4; v++) {
                             if (le[v] > lb[v]) {
                                 // top bit: the bucket the query itself would be stored in (same sub-index, same path)
+#if defined(DPF_PROBE_ABLATE) && (DPF_PROBE_ABLATE & 2)
+                                if (pos < (uint32_t)p.q_leaf_cap && leaf[v >> 1][v & 1] == 0xfffffff0u)
+#else
                                 if (pos < (uint32_t)p.q_leaf_cap)
+#endif
                                     p.q_leaves[q * p.q_leaf_cap + pos] = make_uint2(leaf[v >> 1][v & 1], place[v] | (own_hit[v >> 1][v & 1] ? 0x80000000u : 0u));
                                 pos++;
                             }
@@ -443,8 +451,12 @@ __global__ __launch_bounds__(MODE == 1 ? 1024 : 256, MODE == 1 ? 4 : 8) void k_p
             p.raw[q] = r;
             p.bound[q] = (int64_t)(r < (unsigned long long)range ? r : (unsigned long long)range);
             if (p.q_leaves) {
+#if defined(DPF_PROBE_ABLATE) && (DPF_PROBE_ABLATE & 2)
+                p.q_leaf_cnt[q] = 0;
+#else
                 p.q_leaf_cnt[q] = (int32_t)s_nleaf;
                 if (s_nleaf > (uint32_t)p.q_leaf_cap) *p.q_leaf_overflow = 1;
+#endif
             }
         }
     } else if (MODE == 1) {
