@@ -296,6 +296,15 @@ int dpf_get_stats(dpf_index *ix, dpf_stats *out);
 int dpf_snapshot_sizes(dpf_index *ix, int64_t *sizes);
 int dpf_snapshot_copy(dpf_index *ix, uint32_t *roots, uint32_t *dnodes, uint32_t *leaf_off, int32_t *ids);
 
+/* What the probe stage of the last bucket-major top-k batch counted, for inspection and cross-checks (what summing
+ * the sizes of the lists RandomDrawTreeMap.getSimilarWithStepWiseFaster, RDT:742-797, concatenates would show):
+ * bucket_counts[num_leaves] = queries that reached each bucket, ids_visited[nq] = bucket entries met per query over
+ * its distinct buckets, buckets_reached[nq] = distinct non-empty buckets per query, bucket_lists[nq][list_cap] = the
+ * bucket numbers themselves in no particular order (as far as the handle remembered them: DPF_OPT_BUCKET_LIST_CAP;
+ * 0xffffffff padded).  NULL skips an array. */
+int dpf_last_incidences(dpf_index *ix, uint32_t *bucket_counts, uint64_t *ids_visited, int32_t *buckets_reached,
+                        uint32_t *bucket_lists, int32_t list_cap);
+
 /* Device time of the dominant kernel of the last *_topk* call, measured with HIP
  * events on the stream the kernel ran on, and the bytes that launch has to move by
  * its own definition: the gather rerank (dpf_stats.last_path 0) reads every
@@ -329,10 +338,14 @@ enum {
                                         (default 0: an upper bound of the k-th best distance from the fp16 copies) */
     DPF_OPT_KEEP_FORWARDED = 11,     /* 1: every row the scan forwarded is scored exactly (default 0: rows forwarded under a
                                         threshold the query has tightened past since are dropped before the exact rerank) */
-    DPF_OPT_SIDE_STREAM = 12         /* 0: every kernel of a batch is enqueued on the caller's stream (default 1: from the
+    DPF_OPT_SIDE_STREAM = 12,        /* 0: every kernel of a batch is enqueued on the caller's stream (default 1: from the
                                         handle's second batch on, the kernels that build the bucket lists run on a stream
                                         of the handle's own beside those that find the first radii; both are ordered
                                         behind the caller's stream and joined to it again before the scan) */
+    DPF_OPT_PROBE_LANES = 13         /* the counting pass of the bucket-major path: 1 = a lane per (query, table, sub-index) that
+                                        walks the hash's own path once and reads the sibling slots on it, 0 = a lane per probe (one
+                                        bit flip of the hash) as the pass that materialises the Sets does, -1 (default) = the first
+                                        where a query probes at most 16 (table, sub-index) pairs, the second otherwise */
 };
 int dpf_set_option(dpf_index *ix, int32_t option, int64_t value);
 

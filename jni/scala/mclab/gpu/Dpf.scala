@@ -34,6 +34,7 @@ object Dpf {
   val OptExactSeeds = 10
   val OptKeepForwarded = 11
   val OptSideStream = 12
+  val OptProbeLanes = 13
   // DPF_FLAG_* of dpf_config.flags
   val FlagHashOnly = 1
   val FlagGatherOnly = 2

@@ -49,12 +49,12 @@ EXPORTS = (
     "dpf_query_topk", "dpf_query_topk_device", "dpf_rerank", "dpf_merge_topk_device", "dpf_merge_topk_packed_device",
     "dpf_subindex_distribution", "dpf_get_stats", "dpf_last_rerank_profile", "dpf_set_profiling",
     "dpf_save", "dpf_load", "dpf_get_config", "dpf_snapshot_sizes", "dpf_snapshot_copy", "dpf_set_option", "dpf_query_topk_device_static",
-    "dpf_load_shard", "dpf_set_probe_mode", "dpf_host_alloc", "dpf_host_free",
+    "dpf_load_shard", "dpf_set_probe_mode", "dpf_host_alloc", "dpf_host_free", "dpf_last_incidences",
 )
 
 # dpf_set_option keys (include/dpf.h)
 OPTION = {"emit_cap": 1, "bucket_list_cap": 2, "sync_sizes": 3, "first_pass_permille": 4, "seed_sample": 5,
-          "short_rerank": 6, "projection_min_rows": 7, "scan_passes": 8, "early_pass_permille": 9, "exact_seeds": 10, "keep_forwarded": 11, "side_stream": 12}
+          "short_rerank": 6, "projection_min_rows": 7, "scan_passes": 8, "early_pass_permille": 9, "exact_seeds": 10, "keep_forwarded": 11, "side_stream": 12, "probe_lanes": 13}
 
 _lib = None
 
@@ -131,6 +131,8 @@ def lib():
     L.dpf_snapshot_copy.argtypes = [vp, vp, vp, vp, vp]
     L.dpf_get_config.restype = C.c_int
     L.dpf_get_config.argtypes = [vp, C.POINTER(DpfConfig)]
+    L.dpf_last_incidences.restype = C.c_int
+    L.dpf_last_incidences.argtypes = [vp, vp, vp, vp, vp, C.c_int32]
     L.dpf_host_alloc.restype = C.c_int
     L.dpf_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
     L.dpf_host_free.restype = None
@@ -381,6 +383,18 @@ class DpfIndex:
         st = DpfStats()
         self._check(self.L_.dpf_get_stats(self.h, C.byref(st)))
         return {n: getattr(st, n) for n, _ in DpfStats._fields_}
+
+    def last_incidences(self, nq, list_cap=0):
+        """(bucket_counts [num_leaves] uint32, ids_visited [nq] uint64, buckets_reached [nq] int32, bucket_lists
+        [nq, list_cap] uint32) of the last bucket-major top-k batch of nq queries."""
+        nl = self.stats()["num_leaves"]
+        bc = np.zeros(nl, dtype=np.uint32)
+        raw = np.zeros(nq, dtype=np.uint64)
+        br = np.zeros(nq, dtype=np.int32)
+        bl = np.zeros((nq, max(list_cap, 1)), dtype=np.uint32)
+        self._check(self.L_.dpf_last_incidences(self.h, bc.ctypes.data, raw.ctypes.data, br.ctypes.data,
+                                                bl.ctypes.data if list_cap > 0 else None, list_cap))
+        return bc, raw, br, bl
 
     def last_rerank_profile(self):
         ms = C.c_double()

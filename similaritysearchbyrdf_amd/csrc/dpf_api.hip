@@ -245,6 +245,8 @@ struct dpf_index {
     int32_t opt_emit_cap = 0, opt_bucket_list_cap = 0, opt_first_permille = 150, opt_seed_cap = -1;   // seed sample: -1 = by the forest's bucket sizes
     int32_t auto_seed_cap = 256;             // what -1 stands for, set when the forest is built (seed_sample_for)
     int32_t opt_scan_passes = 0, opt_early_permille = 40;   // passes: 0 = by row length (3 from 16 steps on), 2 or 3
+    int32_t opt_probe_lanes = -1;                     // -1: by the number of (table, sub-index) pairs a query probes
+    int32_t last_q_leaf_cap = 0;                      // bucket-list capacity of the last bucket-major batch
     bool opt_sync_sizes = false, opt_short_rerank = true, opt_exact_seeds = false, opt_keep_forwarded = false, opt_side_stream = true;
     int64_t opt_projection_min_rows = 4096;           // batches of at least this many vectors hash on the matrix cores (0: never)
 };
@@ -1293,13 +1295,24 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
         const int64_t most = (int64_t)L * 28 * nsub;          // every probe in a bucket of its own
         pp.q_leaf_cap = (int32_t)std::min<int64_t>(most, 4096);
         if (ix->opt_bucket_list_cap > 0) pp.q_leaf_cap = ix->opt_bucket_list_cap;
+        ix->last_q_leaf_cap = pp.q_leaf_cap;
         HIPCHECK(ix, ix->ws_q_leaves.ensure((size_t)nq * pp.q_leaf_cap * 8));
         HIPCHECK(ix, ix->ws_q_leaf_cnt.ensure((size_t)nq * 4));
         pp.q_leaves = ix->ws_q_leaves.as<uint2>();
         pp.q_leaf_cnt = ix->ws_q_leaf_cnt.as<int32_t>();
         pp.q_leaf_overflow = (int32_t *)flag_block_of(ix) + 1;
     }
-    launch_probe(0, pp, nq, stream);
+    {
+        // The counting pass: a lane per (query, table, sub-index) where a query has few of those (a single tree: a wave
+        // per table leaves k_probe<0> mostly idle; 18 instead of 25 us on 10k queries), a lane per probe otherwise (30
+        // trees, 4 sub-indexes each: 215 us against 230; the 7.7 M returning atomics on the incidence counters, not the
+        // walk, are what the time goes to there - without them 99 us against 164).  DPF_OPT_PROBE_LANES pins either.
+        int nsub = 0;
+        for (int s2 = 0; s2 < ix->geo.num_parts; s2++) nsub += __builtin_popcount((unsigned)s2) <= steps;
+        const int lanes_per_query = (pp.t_end - pp.t_begin) * nsub;
+        const bool lanes = ix->opt_probe_lanes >= 0 ? ix->opt_probe_lanes != 0 : lanes_per_query <= 16;
+        if (!(lanes && launch_probe_lanes(pp, nq, stream))) launch_probe(0, pp, nq, stream);
+    }
     HIPCHECK(ix, ix->ws_unit_off.ensure((size_t)(nl + 2) * 8));
     // The two totals of the batch (bucket incidences, work units) size leaf_queries[] and units[].  The first
     // batch of a handle reads them back here; later batches do not wait: the kernels behind this point take the
@@ -1946,6 +1959,10 @@ extern "C" int dpf_set_option(dpf_index *ix, int32_t option, int64_t value)
     case DPF_OPT_EXACT_SEEDS:
         ix->opt_exact_seeds = value != 0;
         return DPF_OK;
+    case DPF_OPT_PROBE_LANES:
+        if (value < -1 || value > 1) return fail(ix, DPF_EINVAL, "dpf_set_option: probe lanes must be -1 (by the forest), 0 or 1");
+        ix->opt_probe_lanes = (int32_t)value;
+        return DPF_OK;
     case DPF_OPT_PROJECTION_MIN_ROWS:
         if (value < 0) return fail(ix, DPF_EINVAL, "dpf_set_option: the row count must not be negative");
         ix->opt_projection_min_rows = value;
@@ -2034,6 +2051,30 @@ extern "C" int dpf_get_stats(dpf_index *ix, dpf_stats *out)
     ix->st.resident_ids = 0;
     for (uint32_t len : ix->h_leaf_len) ix->st.resident_ids += len;
     *out = ix->st;
+    return DPF_OK;
+}
+
+extern "C" int dpf_last_incidences(dpf_index *ix, uint32_t *bucket_counts, uint64_t *ids_visited, int32_t *buckets_reached,
+                                   uint32_t *bucket_lists, int32_t list_cap)
+{
+    if (!ix) return DPF_EINVAL;
+    if (!ix->last_valid || ix->last_path != 1 || ix->last_nq <= 0) return fail(ix, DPF_EINVAL, "dpf_last_incidences: the last batch did not take the bucket-major path");
+    HIPCHECK(ix, hipSetDevice(ix->cfg.device));
+    HIPCHECK(ix, hipDeviceSynchronize());
+    if (bucket_counts && ix->num_leaves > 0) HIPCHECK(ix, hipMemcpy(bucket_counts, lq_cnt_of(ix), (size_t)ix->num_leaves * 4, hipMemcpyDeviceToHost));
+    if (ids_visited) HIPCHECK(ix, hipMemcpy(ids_visited, ix->ws_raw.p, (size_t)ix->last_nq * 8, hipMemcpyDeviceToHost));
+    if (buckets_reached) HIPCHECK(ix, hipMemcpy(buckets_reached, ix->ws_q_leaf_cnt.p, (size_t)ix->last_nq * 4, hipMemcpyDeviceToHost));
+    if (bucket_lists && list_cap > 0) {
+        const int32_t cap = ix->last_q_leaf_cap;
+        std::vector<uint2> row((size_t)std::max(cap, 1));
+        std::vector<int32_t> cnt((size_t)ix->last_nq);
+        HIPCHECK(ix, hipMemcpy(cnt.data(), ix->ws_q_leaf_cnt.p, cnt.size() * 4, hipMemcpyDeviceToHost));
+        for (int64_t q = 0; q < ix->last_nq; q++) {
+            const int32_t n = std::min(std::min(cnt[(size_t)q], cap), list_cap);
+            if (n > 0) HIPCHECK(ix, hipMemcpy(row.data(), ix->ws_q_leaves.as<uint2>() + (size_t)q * cap, (size_t)n * 8, hipMemcpyDeviceToHost));
+            for (int32_t i = 0; i < list_cap; i++) bucket_lists[(size_t)q * list_cap + i] = i < n ? row[(size_t)i].x : 0xffffffffu;
+        }
+    }
     return DPF_OK;
 }
 

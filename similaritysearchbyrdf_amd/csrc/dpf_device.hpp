@@ -67,6 +67,10 @@ struct ProbeParams {
     int32_t *seed_cnt;        // [nq]
     int32_t seed_cap;
     const int32_t *abort = nullptr;   // k_fill_lists: when set and non-zero the batch is being abandoned, write nothing
+    // k_probe_lanes: the bit patterns with at most `steps` of the pb sub-index bits set (RDT:613-621: a query probes the
+    // sub-indexes own ^ sub_delta[j]), filled by launch_probe_lanes
+    int32_t nsub = 0;
+    uint8_t sub_delta[32] = {0};
 };
 
 // Bucket-major scan: every touched bucket's rows are loaded once and scored
@@ -150,6 +154,9 @@ size_t project_codes_bytes(const HashParams &p, int64_t n);
 hipError_t launch_hash_mfma(int dtype, const void *X, int64_t x_stride, int64_t n, const HashParams &p, const ProjectWs &ws,
                             int32_t *hashes, int32_t *parts, hipStream_t stream);
 void launch_probe(int mode, const ProbeParams &p, int64_t nq, hipStream_t stream);
+// what launch_probe(0, ...) computes for the bucket-major path (lq_cnt and q_leaves set), one lane per (query, table,
+// sub-index) instead of one lane per probe; false (nothing launched) when the configuration is outside its limits
+bool launch_probe_lanes(ProbeParams p, int64_t nq, hipStream_t stream);
 void launch_fill_lists(const ProbeParams &p, int64_t nq, hipStream_t stream);
 void launch_seed_sample(const ProbeParams &p, int64_t nq, hipStream_t stream);
 void launch_leafscan(int metric, const LeafScanParams &p, hipStream_t stream);

@@ -467,6 +467,187 @@ __global__ __launch_bounds__(MODE == 1 ? 1024 : 256, MODE == 1 ? 4 : 8) void k_p
     }
 }
 
+// ---------------------------------------------------------------------------
+// k_probe_lanes: the counting pass of the bucket-major path (what k_probe<0> computes when it also
+// histograms the incidences and remembers each query's buckets), one LANE per (query, table, sub-index).
+//
+// The <= 28 probes of one (query, table, sub-index) - the hash with one bit flipped each (RDT:753-756) - reach
+// few distinct buckets, and which ones follows from the hash's OWN path through the trie: a flipped bit
+// that belongs to a level the own path passes through as a directory sends the probe into the sibling slot
+// of that directory (flipped bit b of the level: slot ^ (1 << b)) and from there down along the hash's own
+// lower bits; it ends in a subtree no other probe enters.  Every other flipped bit - below the level at which
+// the own path ends in a bucket, or in the bits above the trie's (max_level + 1) * nbits - leaves the path as
+// it is and ends in the hash's own bucket.  So the lane walks the own path once, reads at every directory on
+// it the nbits sibling slots (one 4 * dns-byte directory = one or a few cache lines), follows the siblings
+// that are directories down, and takes the own bucket once if any probe reaches it.  k_probe<0> spends a
+// lane per probe and most of its loads on addresses the neighbouring lanes load too; the address path of the
+// memory pipeline is paid per instruction, not per distinct address.
+// ---------------------------------------------------------------------------
+constexpr int PL_THREADS = 256;
+// What a lane finds goes through a queue in LDS and is counted from there by ALL lanes of the workgroup, one queue
+// entry per lane: the buckets one lane finds at one level are siblings - neighbouring bucket numbers, so their
+// offsets and incidence counters share cache lines - and the memory pipeline merges the lanes of one instruction
+// that touch one line.  Counted by the finding lane itself, bucket by bucket, every atomic of an instruction went
+// to a line of its own: 380 us instead of 100 on 10k queries over 30 tables.
+template <int NB>   // bits per trie level (dirNodeSize = 1 << NB)
+__global__ __launch_bounds__(PL_THREADS) void k_probe_lanes(ProbeParams p, int64_t nq, int qpw, int T)
+{
+    constexpr int PER = NB + 1;                              // buckets a lane can find at one level: NB siblings and its own
+    __shared__ uint32_t s_nleaf[32];
+    __shared__ unsigned long long s_raw[32];
+    __shared__ uint32_t s_queue[PL_THREADS * PER];           // bucket | own-bucket flag (bit 31) ...
+    __shared__ uint8_t s_queue_q[PL_THREADS * PER];          // ... and the query (of this workgroup's) it belongs to
+    __shared__ uint32_t s_qn;
+    const int tid = threadIdx.x;
+    const int64_t q0 = (int64_t)blockIdx.x * qpw;
+    const int nql = (int)((nq - q0 < qpw) ? nq - q0 : qpw);
+    if (tid < 32) { s_nleaf[tid] = 0; s_raw[tid] = 0; }
+    if (tid == 0) s_qn = 0;
+    __syncthreads();
+    const int P = 1 << p.pb;
+    constexpr uint32_t mask = (1u << NB) - 1u;
+    constexpr int dns = 1 << NB;
+    const int trie_bits = (p.max_level + 1) * NB;
+    for (int x0 = 0; x0 < nql * T; x0 += PL_THREADS) {       // (uniform over the workgroup: barriers inside)
+        const int x = x0 + tid;
+        const bool live = x < nql * T;
+        const int ql = live ? x / T : 0, r = x - ql * T;
+        const int t = p.t_begin + (live ? r / p.nsub : 0), j = live ? r - (r / p.nsub) * p.nsub : 0;
+        const int64_t q = q0 + ql;
+        uint32_t h = 0, node = 0;
+        int nprobe = 0;
+        bool own_sub = false;
+        if (live) {
+            h = (uint32_t)p.hashes[q * p.L + t];
+            const int part = p.parts[q * p.L + t];
+            // RDT:753: 32 - numberOfLeadingZeros(h) - 4 probes; negative for 0 <= h < 8.  The keyed walk (RDT:630-675)
+            // has no probe list: it looks up the hash itself, whatever its value.
+            nprobe = p.probe_own ? 1 : 32 - (h ? __clz(h) : 32) - 4;
+            if (nprobe < 0 && j == 0) atomicAdd(p.short_hash_events, 1ull);
+            const int sub = part ^ (int)p.sub_delta[j];
+            own_sub = sub == part;
+            if (nprobe > 0 && ((p.sub_mask >> sub) & 1u)) node = p.roots[((size_t)t * P + sub) * p.seg + (h >> p.bucket_bits)];
+        }
+        for (int level = p.max_level; level >= 0; --level) {
+            if (!__syncthreads_or(node != 0)) break;         // (also: the queue of the level before has been read out)
+            uint32_t lf[PER];
+#pragma unroll
+            for (int b = 0; b < PER; b++) lf[b] = NO_LEAF;
+            if (node != 0) {
+                const int shift = level * NB;
+                const uint32_t slot = (h >> shift) & mask;
+                const uint32_t *dn = p.dnodes + (size_t)node * dns;
+                // the own slot and the sibling slots of this level's flipped bits, in flight together
+                uint32_t w[NB];
+#pragma unroll
+                for (int b = 0; b < NB; b++)
+                    w[b] = (!p.probe_own && shift + b < nprobe) ? dn[slot ^ (1u << b)] : 0u;
+                const uint32_t w_own = dn[slot];
+#pragma unroll
+                for (int b = 0; b < NB; b++) {
+                    if (w[b] & 1u) lf[b] = w[b] >> 1;
+#if defined(DPF_PROBE_ABLATE) && (DPF_PROBE_ABLATE & 4)
+                    else if (w[b] == 0xfffffff0u) {
+#else
+                    else if (w[b]) {
+#endif
+                        // a sibling that is a directory: down along the hash's own lower bits
+                        uint32_t n2 = w[b] >> 1;
+                        for (int l2 = level - 1; l2 >= 0; --l2) {
+                            const uint32_t w2 = p.dnodes[(size_t)n2 * dns + ((h >> (l2 * NB)) & mask)];
+                            if (w2 & 1u) { lf[b] = w2 >> 1; break; }
+                            if (w2 == 0) break;
+                            n2 = w2 >> 1;
+                        }
+                    }
+                }
+                // the own path: on through a directory; a bucket is reached by the probes whose flipped bit lies below
+                // this level or above the trie's bits (and by the keyed walk)
+                node = 0;
+                if (w_own & 1u) {
+                    if (p.probe_own || level > 0 || nprobe > trie_bits) lf[NB] = (w_own >> 1) | (own_sub ? 0x80000000u : 0u);
+                } else {
+                    node = w_own >> 1;
+                }
+                int mine = 0;
+#pragma unroll
+                for (int b = 0; b < PER; b++) mine += lf[b] != NO_LEAF;
+                if (mine) {
+                    uint32_t at = atomicAdd(&s_qn, (uint32_t)mine);
+#pragma unroll
+                    for (int b = 0; b < PER; b++)
+                        if (lf[b] != NO_LEAF) { s_queue[at] = lf[b]; s_queue_q[at] = (uint8_t)ql; at++; }
+                }
+            }
+            __syncthreads();
+            // every lane counts one queue entry at a time
+            const uint32_t n = s_qn;
+            for (uint32_t e = tid; e < n; e += PL_THREADS) {
+                const uint32_t ent = s_queue[e], leaf = ent & 0x7fffffffu;
+                const int eq = s_queue_q[e];
+#if defined(DPF_PROBE_ABLATE) && (DPF_PROBE_ABLATE & 8)
+                const uint32_t lb = 0, le = 1;
+#else
+                const uint32_t lb = p.leaf_off[leaf], le = p.leaf_off[leaf + 1];
+#endif
+                if (le > lb) {
+#if defined(DPF_PROBE_ABLATE) && (DPF_PROBE_ABLATE & 1)
+                    const uint32_t place = leaf == 0xfffffff0u ? atomicAdd(&p.lq_cnt[0], 1u) : 0u;
+#else
+                    const uint32_t place = atomicAdd(&p.lq_cnt[leaf], 1u);
+#endif
+                    const uint32_t pos = atomicAdd(&s_nleaf[eq], 1u);
+                    atomicAdd(&s_raw[eq], (unsigned long long)(le - lb));
+                    // top bit: the bucket the query itself would be stored in (own sub-index, own path)
+                    if (pos < (uint32_t)p.q_leaf_cap)
+                        p.q_leaves[(q0 + eq) * p.q_leaf_cap + pos] = make_uint2(leaf, place | (ent & 0x80000000u));
+                }
+            }
+            __syncthreads();
+            if (tid == 0) s_qn = 0;
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    const int64_t range = p.row_end - p.row_begin;
+    if (tid < nql) {
+        const int64_t q = q0 + tid;
+        const unsigned long long rr = s_raw[tid];
+        p.raw[q] = rr;
+        p.bound[q] = (int64_t)(rr < (unsigned long long)range ? rr : (unsigned long long)range);
+#if defined(DPF_PROBE_ABLATE) && (DPF_PROBE_ABLATE & 2)
+        p.q_leaf_cnt[q] = 0;
+#else
+        p.q_leaf_cnt[q] = (int32_t)s_nleaf[tid];
+        if (s_nleaf[tid] > (uint32_t)p.q_leaf_cap) *p.q_leaf_overflow = 1;
+#endif
+    }
+}
+
+bool launch_probe_lanes(ProbeParams p, int64_t nq, hipStream_t stream)
+{
+    if (nq <= 0) return true;
+    if (!p.lq_cnt || !p.q_leaves || p.nbits < 5 || p.nbits > 8 || p.dns != (1 << p.nbits) || p.pb > 5) return false;
+    p.nsub = 0;
+    for (int d = 0; d < (1 << p.pb); d++)
+        if (__builtin_popcount((unsigned)d) <= p.steps) p.sub_delta[p.nsub++] = (uint8_t)d;
+    const int T = (p.t_end - p.t_begin) * p.nsub;
+    if (T <= 0) return false;
+    // whole queries per workgroup (their bucket counters live in LDS); few per workgroup when a query has few lanes,
+    // so that small forests still spread over the chip
+    int qpw = PL_THREADS / T;
+    if (qpw < 1) qpw = 1;
+    if (qpw > 32) qpw = 32;
+    const int64_t grid = (nq + qpw - 1) / qpw;
+    switch (p.nbits) {
+    case 5: hipLaunchKernelGGL((k_probe_lanes<5>), dim3((unsigned)grid), dim3(PL_THREADS), 0, stream, p, nq, qpw, T); break;
+    case 6: hipLaunchKernelGGL((k_probe_lanes<6>), dim3((unsigned)grid), dim3(PL_THREADS), 0, stream, p, nq, qpw, T); break;
+    case 7: hipLaunchKernelGGL((k_probe_lanes<7>), dim3((unsigned)grid), dim3(PL_THREADS), 0, stream, p, nq, qpw, T); break;
+    default: hipLaunchKernelGGL((k_probe_lanes<8>), dim3((unsigned)grid), dim3(PL_THREADS), 0, stream, p, nq, qpw, T); break;
+    }
+    return true;
+}
+
 // k_fill_lists + k_seed_sample: what k_probe<2> does, from the bucket lists k_probe<0> recorded instead of a
 // second walk of the forest.  k_fill_lists writes the query into its place in every bucket's list (it needs the
 // lists' offsets); k_seed_sample copies ids of the query's first buckets into its seed sample (it needs only what
