@@ -102,6 +102,11 @@ def ground_truth_l2(torch, dX, dQ, k, chunk=500):
     return torch.cat(out).cpu().numpy()
 
 
+def peak_rss_mb():
+    import resource
+    return resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0
+
+
 def cpu_model():
     try:
         with open("/proc/cpuinfo") as f:
@@ -312,6 +317,11 @@ def main():
                          "times the Infinity Cache; 0 = skip")
     ap.add_argument("--rerank", default="auto", choices=["auto", "gather"],
                     help="auto: bucket-major fp16 scan + exact rerank where it applies; gather: per-query fp64 gather kernel")
+    ap.add_argument("--stream-fit", action="store_true",
+                    help="c5 only: the base is never held on the host - every rank generates it chunk by chunk (chunk-seeded "
+                         "recipe: any rank can produce any row range), hashes each chunk on the device and keeps the rows of its "
+                         "shard; the forest is built once after the last chunk.  Skips what needs the whole base on the host "
+                         "(recall, CPU baseline, gather check)")
     ap.add_argument("--verify", action="store_true", help="rank 0 also runs an unsharded index and compares the merged ids")
     ap.add_argument("--mode", default="auto", choices=["auto", "rows", "tables"],
                     help="N > 1: rows = base rows x query batch sharded (forest replicated); tables = trees x query batch "
@@ -341,7 +351,22 @@ def main():
         else:
             dist.init_process_group("gloo")
 
-    params, X, Q, pick, steps = workload(args.workload, args.n, args.nq, args.dim)
+    stream_fit = args.stream_fit
+    if stream_fit:
+        if args.workload != "c5":
+            raise SystemExit("--stream-fit is the bring-up of c5-sized bases (the other workloads fit the host easily)")
+        d_ = args.dim or 768
+        params = synthetic.make_family(d_, table_num=10, permutation_num=3, chain_length=32, family="angle",
+                                       family_size=d_, partition_bits=3, orthogonal=True)
+        params.update(bucket_overflow=500, dir_node_size=32, bucket_bits=28, exclude_self="compat")
+        X, steps = None, 1
+        q_batches = synthetic.unit_gaussian_queries(args.n, d_, args.nq, batches=max(1, args.batches))
+        if max(1, args.batches) == 1:
+            q_batches = [q_batches]
+        Q, pick = q_batches[0]
+        args.no_recall = args.no_cpu_baseline = args.no_gather_check = args.no_out_of_sample = True
+    else:
+        params, X, Q, pick, steps = workload(args.workload, args.n, args.nq, args.dim)
     if args.rerank == "gather":
         params["flags"] = 2          # DPF_FLAG_GATHER_ONLY
     if args.full_filter:
@@ -350,11 +375,12 @@ def main():
         params["flags"] = int(params.get("flags", 0)) | 16         # DPF_FLAG_NO_INT8
     if args.search_steps is not None:
         steps = args.search_steps
-    n, nq, k = X.shape[0], Q.shape[0], args.k
+    n, nq, k = (args.n if stream_fit else X.shape[0]), Q.shape[0], args.k
+    dim_ = Q.shape[1]
     nb = max(1, args.batches)
     host_batches = [(Q, pick.astype(np.int32))]
     for b in range(1, nb):
-        qb, pb_ = synthetic.more_queries(QUERY_RECIPE[args.workload], X, nq, seed=9000 + b)
+        qb, pb_ = q_batches[b] if stream_fit else synthetic.more_queries(QUERY_RECIPE[args.workload], X, nq, seed=9000 + b)
         host_batches.append((qb, pb_.astype(np.int32)))
     grid = tuple(int(v) for v in args.grid.lower().split("x")) if args.grid else None
     sharded = ShardedDpf(params, n, metric=args.metric, top_k=k, dtype=np.float32, device=local, rank=rank, world=world,
@@ -364,7 +390,10 @@ def main():
         name, _, value = ov.partition("=")
         ix.set_option(name, int(value))
     t0 = time.time()
-    sharded.fit(X)
+    if stream_fit:
+        sharded.fit_stream(synthetic.unit_gaussian_chunks(n, dim_), total_rows=n)
+    else:
+        sharded.fit(X)
     fit_s = time.time() - t0
 
     dev_batches = [(torch.from_numpy(q).to(dev), torch.from_numpy(p).to(dev)) for q, p in host_batches]
@@ -427,7 +456,7 @@ def main():
         del pin_batches, pin_out
         h2h = {"value": nq * args.steps / dth, "ms_per_step": dth / args.steps * 1e3,
                "h2d_d2h_and_sync_ms_per_step": (dth - dt) / args.steps * 1e3,
-               "bytes_per_step": {"h2d": int(nq * X.shape[1] * 4 + nq * 4), "d2h": int(nq * k * 12)},
+               "bytes_per_step": {"h2d": int(nq * dim_ * 4 + nq * 4), "d2h": int(nq * k * 12)},
                "host_memory": "pageable (numpy arrays handed to dpf_query_topk; staged through the handle's pinned area in 1 MiB pieces)",
                "pinned": {"value": nq * args.steps / dtp, "ms_per_step": dtp / args.steps * 1e3,
                           "h2d_d2h_and_sync_ms_per_step": (dtp - dt) / args.steps * 1e3,
@@ -482,7 +511,10 @@ def main():
     if args.verify and rank == 0:
         from similaritysearchbyrdf_amd._lib import DpfIndex
         full = DpfIndex(params, metric=args.metric, top_k=k, dtype=np.float32, device=local)
-        full.fit(X)
+        if stream_fit:
+            full.fit_stream(synthetic.unit_gaussian_chunks(n, dim_), total_rows=n)
+        else:
+            full.fit(X)
         want_ids, _ = full.query_topk(host_batches[0][1], Q, steps=steps, k=k)
         if not np.array_equal(want_ids, final_ids):
             raise SystemExit("verify failed: merged sharded result differs from the unsharded index")
@@ -595,7 +627,7 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %d-d float32, %d base / %d queries, %d trees, %d partition bits, "
                                    "bucket overflow %d, %d-step search, top-%d by %s" % (
-                                       args.workload, X.shape[1], n, nq, ix.L, ix.pb, params["bucket_overflow"],
+                                       args.workload, dim_, n, nq, ix.L, ix.pb, params["bucket_overflow"],
                                        steps, k, args.metric),
                        "arithmetic": "rows and queries float32 in HBM; hashing and the exact rerank in float64; "
                                      "the bucket-major filter in " + (
@@ -608,6 +640,10 @@ def main():
                        "batches_in_timed_loop_by_list_sizing_on_rank0": sizing,
                        "recall_at_10": recall, "recall_measured_on": "batch 0 of the rotation",
                        "fit_seconds": round(fit_s, 3),
+                       "fit": ("streamed: %d-row chunks generated, hashed and sharded one at a time, forest built once "
+                               "(includes the host's generation of every chunk)" % synthetic.ROW_CHUNK) if stream_fit else "whole base from host memory",
+                       "host_peak_rss_mb_on_rank0": round(peak_rss_mb(), 1),
+                       "resident_base_mb_on_rank0": round(st["base_bytes"] / 1e6, 1),
                        "fit_ms_on_rank0": {"copy_in_and_hash": round(st["fit_ms_hash"], 1),
                                            "forest_build_on_device": round(st["fit_ms_forest"], 1)},
                        "rerank_path": ("bucket-major %s scan + exact fp64 rerank" % ("int8" if st["last_scan_int8"] == 1 else "fp16"))

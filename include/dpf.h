@@ -176,6 +176,9 @@ int dpf_set_sampling_index(dpf_index *ix, const int32_t *sampling_index);
  * would have grown by inserting the ids in ascending order) is derived on the device from
  * the hashes of all ids fitted so far. */
 int dpf_fit(dpf_index *ix, const void *X, int64_t n);
+/* (A base too large to hold on the host at once is streamed in: DPF_OPT_EXPECTED_ROWS = total, DPF_OPT_DEFER_BUILD = 1,
+ * dpf_fit chunk after chunk - every handle of a sharded index sees every chunk, hashes it and keeps the rows of its shard -
+ * then DPF_OPT_DEFER_BUILD = 0 and dpf_fit(ix, NULL, 0).) */
 
 /* LocalitySensitiveHasher.hash for every table (Hasher:44-54 -> LSH:135-166)
  * and LocalitySensitivePartitioner.getPartition of each hash (Part:40-59):
@@ -342,10 +345,16 @@ enum {
                                         handle's second batch on, the kernels that build the bucket lists run on a stream
                                         of the handle's own beside those that find the first radii; both are ordered
                                         behind the caller's stream and joined to it again before the scan) */
-    DPF_OPT_PROBE_LANES = 13         /* the counting pass of the bucket-major path: 1 = a lane per (query, table, sub-index) that
+    DPF_OPT_PROBE_LANES = 13,        /* the counting pass of the bucket-major path: 1 = a lane per (query, table, sub-index) that
                                         walks the hash's own path once and reads the sibling slots on it, 0 = a lane per probe (one
                                         bit flip of the hash) as the pass that materialises the Sets does, -1 (default) = the first
                                         where a query probes at most 16 (table, sub-index) pairs, the second otherwise */
+    DPF_OPT_DEFER_BUILD = 14,        /* 1: dpf_fit only appends - copy-in, hashing, the resident rows - and leaves the forest and the
+                                        scan's copies unbuilt (queries are refused with DPF_ENOTFIT meanwhile); the first dpf_fit
+                                        after the option is cleared (n = 0 will do) builds them once over everything appended.
+                                        For a base streamed in chunk by chunk: one forest build instead of one per chunk */
+    DPF_OPT_EXPECTED_ROWS = 15       /* ids the caller is going to fit in all (0 = unknown): the next dpf_fit sizes the row and hash
+                                        buffers for them at once instead of regrowing them chunk by chunk */
 };
 int dpf_set_option(dpf_index *ix, int32_t option, int64_t value);
 

@@ -35,6 +35,8 @@ object Dpf {
   val OptKeepForwarded = 11
   val OptSideStream = 12
   val OptProbeLanes = 13
+  val OptDeferBuild = 14
+  val OptExpectedRows = 15
   // DPF_FLAG_* of dpf_config.flags
   val FlagHashOnly = 1
   val FlagGatherOnly = 2

@@ -54,7 +54,8 @@ EXPORTS = (
 
 # dpf_set_option keys (include/dpf.h)
 OPTION = {"emit_cap": 1, "bucket_list_cap": 2, "sync_sizes": 3, "first_pass_permille": 4, "seed_sample": 5,
-          "short_rerank": 6, "projection_min_rows": 7, "scan_passes": 8, "early_pass_permille": 9, "exact_seeds": 10, "keep_forwarded": 11, "side_stream": 12, "probe_lanes": 13}
+          "short_rerank": 6, "projection_min_rows": 7, "scan_passes": 8, "early_pass_permille": 9, "exact_seeds": 10, "keep_forwarded": 11, "side_stream": 12, "probe_lanes": 13,
+          "defer_build": 14, "expected_rows": 15}
 
 _lib = None
 
@@ -281,6 +282,19 @@ class DpfIndex:
     def fit(self, X):
         X = self._rows(X)
         self._check(self.L_.dpf_fit(self.h, X.ctypes.data, X.shape[0]))
+
+    def fit_stream(self, chunks, total_rows=0):
+        """Fits a base that arrives chunk by chunk (an iterable of [rows, dim] arrays): every chunk is hashed and the
+        rows of this handle's shard kept as it passes; the forest is built once, after the last chunk."""
+        if total_rows:
+            self.set_option("expected_rows", total_rows)
+        self.set_option("defer_build", 1)
+        try:
+            for X in chunks:
+                self.fit(X)
+        finally:
+            self.set_option("defer_build", 0)
+        self._check(self.L_.dpf_fit(self.h, None, 0))
 
     def hash_batch(self, Q):
         Q = self._rows(Q)

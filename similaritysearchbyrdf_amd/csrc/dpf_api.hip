@@ -245,6 +245,9 @@ struct dpf_index {
     int32_t opt_emit_cap = 0, opt_bucket_list_cap = 0, opt_first_permille = 150, opt_seed_cap = -1;   // seed sample: -1 = by the forest's bucket sizes
     int32_t auto_seed_cap = 256;             // what -1 stands for, set when the forest is built (seed_sample_for)
     int32_t opt_scan_passes = 0, opt_early_permille = 40;   // passes: 0 = by row length (3 from 16 steps on), 2 or 3
+    bool opt_defer_build = false;                     // dpf_fit appends rows and hashes only; the forest is built by the first dpf_fit after it is cleared
+    int64_t opt_expected_rows = 0;                    // ids the caller is going to fit in all: buffers are sized for them at once
+    bool build_pending = false;                       // rows were appended under opt_defer_build and the forest does not cover them yet
     int32_t opt_probe_lanes = -1;                     // -1: by the number of (table, sub-index) pairs a query probes
     int32_t last_q_leaf_cap = 0;                      // bucket-list capacity of the last bucket-major batch
     bool opt_sync_sizes = false, opt_short_rerank = true, opt_exact_seeds = false, opt_keep_forwarded = false, opt_side_stream = true;
@@ -506,6 +509,7 @@ static int check_ready(dpf_index *ix, bool need_fit)
     if (!ix->have_family) return fail(ix, DPF_ENOFAMILY, "hash family not set (dpf_set_hash_family)");
     if (ix->cfg.partition_bits > 0 && !ix->have_part) return fail(ix, DPF_ENOFAMILY, "partitioner not set (dpf_set_partitioner)");
     if (need_fit && (ix->cfg.flags & DPF_FLAG_HASH_ONLY)) return fail(ix, DPF_EINVAL, "this handle was created hash-only");
+    if (need_fit && ix->build_pending) return fail(ix, DPF_ENOTFIT, "rows were appended with DPF_OPT_DEFER_BUILD set: clear it and call dpf_fit (n = 0 will do) to build the forest");
     if (need_fit && !ix->fitted) return fail(ix, DPF_ENOTFIT, "need to fit the data first");
     return DPF_OK;
 }
@@ -825,8 +829,12 @@ extern "C" int dpf_fit(dpf_index *ix, const void *X, int64_t n)
     const int64_t res_end = std::min<int64_t>(ix->row_end, total);
     const int64_t new_rows = std::max<int64_t>(0, res_end - res_begin);
     const size_t row_bytes = (size_t)ix->dpad * ix->elem;
+    // (a caller that streams the base in announces the final size, so that the buffers are not regrown chunk by chunk)
+    const int64_t final_total = std::max<int64_t>(total, ix->opt_expected_rows);
+    if (final_total * L >= (int64_t)0x7fffffff) return fail(ix, DPF_ECAPACITY, "dpf_fit: more than 2^31 (id, table) pairs expected");
+    const int64_t final_rows = std::max<int64_t>(new_rows, std::min<int64_t>(ix->row_end, final_total) - res_begin);
     if (new_rows > ix->base_rows) {
-        size_t need = std::max<size_t>((size_t)new_rows * row_bytes, 16);
+        size_t need = std::max<size_t>((size_t)final_rows * row_bytes, 16);
         if (need > ix->d_base.cap) {
             DevBuf nb;
             HIPCHECK(ix, nb.ensure(need));
@@ -836,8 +844,8 @@ extern "C" int dpf_fit(dpf_index *ix, const void *X, int64_t n)
         }
     }
     const auto t0 = std::chrono::steady_clock::now();
-    HIPCHECK(ix, ix->d_hashes.grow((size_t)first * L * 4, std::max<size_t>((size_t)total * L * 4, 16)));
-    HIPCHECK(ix, ix->d_parts.grow((size_t)first * L * 4, std::max<size_t>((size_t)total * L * 4, 16)));
+    HIPCHECK(ix, ix->d_hashes.grow((size_t)first * L * 4, std::max<size_t>((size_t)final_total * L * 4, 16)));
+    HIPCHECK(ix, ix->d_parts.grow((size_t)first * L * 4, std::max<size_t>((size_t)final_total * L * 4, 16)));
     if (n > 0) ix->host_hashes_valid = false;
     const int64_t batch = 1 << 17;
     HIPCHECK(ix, ix->ws_stage.ensure((size_t)std::min<int64_t>(batch, std::max<int64_t>(n, 1)) * d * ix->elem));
@@ -858,6 +866,20 @@ extern "C" int dpf_fit(dpf_index *ix, const void *X, int64_t n)
         HIPCHECK(ix, hipDeviceSynchronize());     // the staging buffer is reused by the next batch
     }
     ix->st.fit_ms_hash = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (ix->opt_defer_build) {
+        // streamed fit: the rows and hashes are in place; the copies the scan works on and the forest wait for the
+        // last chunk (the first dpf_fit after DPF_OPT_DEFER_BUILD is cleared, which may carry no rows)
+        ix->base_rows = new_rows;
+        ix->n = total;
+        ix->st.num_vectors = total;
+        ix->st.base_bytes = (int64_t)((size_t)new_rows * row_bytes);
+        ix->fitted = false;
+        ix->build_pending = true;
+        ix->last_valid = false;
+        ix->st.fit_ms_total = ix->st.fit_ms_hash;
+        return DPF_OK;
+    }
+    ix->build_pending = false;
     rc = finish_fit(ix, total, new_rows);
     ix->st.fit_ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return rc;
@@ -1958,6 +1980,13 @@ extern "C" int dpf_set_option(dpf_index *ix, int32_t option, int64_t value)
         return DPF_OK;
     case DPF_OPT_EXACT_SEEDS:
         ix->opt_exact_seeds = value != 0;
+        return DPF_OK;
+    case DPF_OPT_DEFER_BUILD:
+        ix->opt_defer_build = value != 0;
+        return DPF_OK;
+    case DPF_OPT_EXPECTED_ROWS:
+        if (value < 0) return fail(ix, DPF_EINVAL, "dpf_set_option: the row count must not be negative");
+        ix->opt_expected_rows = value;
         return DPF_OK;
     case DPF_OPT_PROBE_LANES:
         if (value < -1 || value > 1) return fail(ix, DPF_EINVAL, "dpf_set_option: probe lanes must be -1 (by the forest), 0 or 1");

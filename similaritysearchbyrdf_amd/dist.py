@@ -192,6 +192,12 @@ class ShardedDpf:
         shard stays in HBM."""
         self.index.fit(X)
 
+    def fit_stream(self, chunks, total_rows=0):
+        """fit() for a base that no rank holds on its host at once: an iterable of [rows, dim] chunks in id order (every
+        rank iterates over the same chunks, e.g. from a row-addressable generator or a memory-mapped file).  Each chunk
+        is hashed on the device and the rows of this rank's shard are kept; the forest is built once at the end."""
+        self.index.fit_stream(chunks, total_rows)
+
     def query_topk(self, d_qids, d_Q, steps, k, out_ids, out_scores, stream=None):
         """Device tensors in, merged device tensors out.  `stream` must be torch's current stream (the
         collective and the copies below are ordered on that one); the device stage blocks the host once

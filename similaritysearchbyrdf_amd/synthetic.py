@@ -176,21 +176,32 @@ def unit_gaussian_rows(lo, hi, dim, seed=777, dtype=np.float32):
     return out
 
 
-def unit_gaussian_queries(n, dim, nq, noise=0.05, seed=777, qseed=778, dtype=np.float32):
+def unit_gaussian_queries(n, dim, nq, noise=0.05, seed=777, qseed=778, dtype=np.float32, batches=1):
     """Queries over the unit_gaussian_rows base: rows picked at random plus N(0, noise^2 / dim) noise per component,
-    normalised again; only the picked rows' chunks are generated.  -> (Q [nq, dim], picked rows)."""
+    normalised again; the base is generated chunk by chunk, once, for all `batches` batches together (only chunks that
+    hold a picked row).  -> (Q [nq, dim], picked rows), or a list of `batches` such pairs."""
     rng = np.random.default_rng(qseed)
-    pick = rng.integers(0, n, size=nq)
-    rows = np.empty((nq, dim), dtype=np.float32)
+    total = nq * batches
+    pick = rng.integers(0, n, size=total)
+    rows = np.empty((total, dim), dtype=np.float32)
     order = np.argsort(pick, kind="stable")
     i = 0
-    while i < nq:
+    while i < total:
         c = int(pick[order[i]]) // ROW_CHUNK
         j = i
-        while j < nq and int(pick[order[j]]) // ROW_CHUNK == c:
+        while j < total and int(pick[order[j]]) // ROW_CHUNK == c:
             j += 1
         chunk = unit_gaussian_rows(c * ROW_CHUNK, min(n, (c + 1) * ROW_CHUNK), dim, seed=seed)
         rows[order[i:j]] = chunk[pick[order[i:j]] - c * ROW_CHUNK]
         i = j
-    q = rows + np.float32(noise / np.sqrt(dim)) * rng.standard_normal((nq, dim), dtype=np.float32)
-    return np.ascontiguousarray(q / np.linalg.norm(q, axis=1, keepdims=True), dtype=dtype), pick
+    q = rows + np.float32(noise / np.sqrt(dim)) * rng.standard_normal((total, dim), dtype=np.float32)
+    Q = np.ascontiguousarray(q / np.linalg.norm(q, axis=1, keepdims=True), dtype=dtype)
+    if batches == 1:
+        return Q, pick
+    return [(np.ascontiguousarray(Q[b * nq:(b + 1) * nq]), pick[b * nq:(b + 1) * nq]) for b in range(batches)]
+
+
+def unit_gaussian_chunks(n, dim, seed=777, dtype=np.float32):
+    """The unit_gaussian_rows base of n rows as a generator of ROW_CHUNK-row pieces in id order."""
+    for lo in range(0, n, ROW_CHUNK):
+        yield unit_gaussian_rows(lo, min(n, lo + ROW_CHUNK), dim, seed=seed, dtype=dtype)

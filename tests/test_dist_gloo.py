@@ -169,3 +169,18 @@ def test_shard_bounds_edge_cases():
     sc = np.array([[[1.0, 3.0, 4.0]], [[1.0, 2.0, 3.0]]])
     mi, ms = merge_topk_host(ids, sc, "l2")
     assert mi.tolist() == [[5, 7, 9]] and ms.tolist() == [[1.0, 2.0, 3.0]]
+
+
+def test_row_addressable_generators():
+    # any rank can produce any row range of the chunk-seeded base without the rows before it
+    from similaritysearchbyrdf_amd import synthetic as S
+    n, dim = 3 * S.ROW_CHUNK + 1234, 8
+    whole = S.unit_gaussian_rows(0, n, dim)
+    assert whole.shape == (n, dim) and np.allclose(np.linalg.norm(whole, axis=1), 1.0, atol=1e-5)
+    for lo, hi in ((0, 10), (S.ROW_CHUNK - 3, S.ROW_CHUNK + 5), (2 * S.ROW_CHUNK, n), (n - 1, n), (500, 500)):
+        assert np.array_equal(S.unit_gaussian_rows(lo, hi, dim), whole[lo:hi])
+    assert np.array_equal(np.concatenate(list(S.unit_gaussian_chunks(n, dim))), whole)
+    Q, pick = S.unit_gaussian_queries(n, dim, 40)
+    assert ((Q * whole[pick]).sum(axis=1) > 0.99).all()              # noisy copies of the picked rows
+    batches = S.unit_gaussian_queries(n, dim, 10, batches=4)
+    assert len(batches) == 4 and np.array_equal(batches[0][0], Q[:10]) and np.array_equal(batches[3][1], pick[30:40])

@@ -1340,3 +1340,51 @@ def test_list_chain_on_the_side_stream_changes_nothing(kind):
         assert np.array_equal(ids.cpu().numpy(), want_i) and np.array_equal(sc.cpu().numpy(), want_s, equal_nan=True)
     for ix in (two, one):
         ix.close()
+
+
+@pytest.mark.gpu
+def test_streamed_fit_equals_whole_fit():
+    # a base that arrives chunk by chunk (DPF_OPT_DEFER_BUILD / DPF_OPT_EXPECTED_ROWS): rows and hashes are appended as
+    # the chunks pass, the forest (put / putInner in id order, RandomDrawTreeMap.java:1558-1790) is built once at the
+    # end and equals the forest of one whole fit; a row-sharded handle keeps only its rows of every chunk
+    from similaritysearchbyrdf_amd._lib import DpfError, DPF_ENOTFIT
+    params, X, Q, pick = make_problem(n=30000, nq=200, bucket_overflow=60, table_num=3, permutation_num=2, n_clusters=12)
+    qids = pick.astype(np.int32)
+    whole = DpfIndex(params, metric="l2")
+    whole.fit(X)
+    want = whole.query_topk(qids, Q, steps=1, k=10)
+    cuts = [0, 1, 4097, 4097, 11000, 25000, 30000]                    # uneven chunks, an empty one among them
+    for kw in (dict(), dict(row_begin=7000, row_end=19000)):
+        ix = DpfIndex(params, metric="l2", **kw)
+        ix.set_option("expected_rows", 30000)
+        ix.set_option("defer_build", 1)
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            ix.fit(X[a:b])
+        with pytest.raises(DpfError) as ei:                           # no forest yet
+            ix.query_topk(qids, Q, steps=1, k=10)
+        assert ei.value.code == DPF_ENOTFIT
+        ix.set_option("defer_build", 0)
+        ix.fit(X[:0])
+        st = ix.stats()
+        assert st["num_vectors"] == 30000 and st["misflag_events"] == whole.stats()["misflag_events"]
+        if not kw:
+            for a, b in zip(ix.snapshot(), whole.snapshot()):
+                assert np.array_equal(a, b)
+            got = ix.query_topk(qids, Q, steps=1, k=10)
+            assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1], equal_nan=True)
+        else:
+            ref = DpfIndex(params, metric="l2", **kw)
+            ref.fit(X)
+            for a, b in zip(ix.snapshot(), ref.snapshot()):
+                assert np.array_equal(a, b)
+            got, exp = ix.query_topk(qids, Q, steps=1, k=10), ref.query_topk(qids, Q, steps=1, k=10)
+            assert np.array_equal(got[0], exp[0]) and np.array_equal(got[1], exp[1], equal_nan=True)
+            assert (got[0][got[0] >= 0] >= 7000).all() and (got[0][got[0] >= 0] < 19000).all()
+            ref.close()
+        # fit_stream: the same through the binding's helper, and more rows afterwards still append
+        ix2 = DpfIndex(params, metric="l2", **kw)
+        ix2.fit_stream((X[a:b] for a, b in zip(cuts[:-1], cuts[1:])), total_rows=30000)
+        for a, b in zip(ix2.snapshot(), ix.snapshot()):
+            assert np.array_equal(a, b)
+        ix2.close()
+        ix.close()
