@@ -190,6 +190,7 @@ def roofline_of(ix, run_batch, nbatches, repeats, n, nq, world, workload_name, s
         out["scan_arithmetic"] = "int8 products, int32 sums (v_mfma_i32_16x16x64_i8)" if int8 else "fp16 products, fp32 sums (v_mfma_f32_16x16x32_f16)"
         out["int8_table_mb" if int8 else "fp16_table_mb"] = table_mb
         out["tile_rows"] = st["tile_rows"]
+        out["rows_read"] = "from a bucket-order copy of the fp16 rows (%.0f MB)" % (st["bucket_order_bytes"] / 1e6) if st["bucket_order_bytes"] else "gathered by id"
         out["mean_tile_occupancy"] = st["resident_ids"] / float(max(1, st["num_tiles"]) * max(1, st["tile_rows"]))
     if rec:
         out["traffic_source"] = rec["file"]
@@ -310,6 +311,9 @@ def main():
                     help="dpf_set_option on the handle before the batches, e.g. --option scan_passes=3 (repeatable)")
     ap.add_argument("--full-filter", action="store_true",
                     help="fp16 copies of every dimension (DPF_FLAG_FULL_FILTER) instead of the leading ones: A/B of the truncated filter")
+    ap.add_argument("--bucket-order-rows", default="auto", choices=["auto", "on", "off"],
+                    help="whether the scan reads a second fp16 copy of the rows laid out in bucket order (DPF_FLAG_[NO_]BUCKET_ORDER_ROWS); "
+                         "auto: the library's rule (line-straddling rows, a table beyond the Infinity Cache, room for the copy)")
     ap.add_argument("--no-int8", action="store_true",
                     help="never scan in int8 (DPF_FLAG_NO_INT8): A/B of the exact integer scan on integer-valued bases (c4)")
     ap.add_argument("--large-table-rows", type=int, default=4_000_000,
@@ -373,6 +377,8 @@ def main():
         params["flags"] = int(params.get("flags", 0)) | 8          # DPF_FLAG_FULL_FILTER
     if args.no_int8:
         params["flags"] = int(params.get("flags", 0)) | 16         # DPF_FLAG_NO_INT8
+    if args.bucket_order_rows != "auto":
+        params["flags"] = int(params.get("flags", 0)) | (64 if args.bucket_order_rows == "on" else 128)
     if args.search_steps is not None:
         steps = args.search_steps
     n, nq, k = (args.n if stream_fit else X.shape[0]), Q.shape[0], args.k

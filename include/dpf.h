@@ -70,7 +70,15 @@ enum { DPF_FLAG_HASH_ONLY = 1,
  * around the mean of the resident rows (queries likewise): distances do not change, the rounding distances the filter
  * has to allow for shrink with the values - rows with a large common offset stay on the bucket-major path instead of
  * forwarding everything (same results; the flag is for A/B). */
-       DPF_FLAG_NO_CENTRE = 32 };
+       DPF_FLAG_NO_CENTRE = 32,
+/* DPF_FLAG_BUCKET_ORDER_ROWS / DPF_FLAG_NO_BUCKET_ORDER_ROWS: the bucket-major scan can read its fp16 rows from a second
+ * copy laid out in bucket order (one row per bucket entry: num_tables times the fp16 table; rows of up to 256 dimensions),
+ * a scan tile's rows then being one contiguous run instead of a gather by id.  With neither flag the handle keeps that
+ * copy when the rows are no whole number of 128-byte lines, the fp16 table exceeds 384 MiB (tables that stay in the
+ * Infinity Cache are read faster by id) and the device has room; the first flag keeps it whenever there is room, the
+ * second never.  Same results either way (dpf_stats.bucket_order_bytes tells what happened). */
+       DPF_FLAG_BUCKET_ORDER_ROWS = 64,
+       DPF_FLAG_NO_BUCKET_ORDER_ROWS = 128 };
 
 /* The subset of the reference's Typesafe-Config keys the path consumes
  * (TestSettings.scala:8-45; read at LSH:19-33, Dense:39-58). */
@@ -146,6 +154,7 @@ typedef struct dpf_stats {
                                         of some function and were hashed again by the exact kernel                       */
     int64_t base8_bytes;             /* HBM bytes of the int8 copy of the resident rows (0: the rows do not allow one)   */
     int64_t last_scan_int8;          /* 1: the last bucket-major batch was scanned in int8, 0: in fp16                    */
+    int64_t bucket_order_bytes;      /* HBM bytes of the bucket-order copy of the fp16 rows (0: the scan gathers its rows by id) */
 } dpf_stats;
 
 typedef struct dpf_index dpf_index;

@@ -44,6 +44,8 @@ object Dpf {
   val FlagFullFilter = 8
   val FlagNoInt8 = 16
   val FlagNoCentre = 32
+  val FlagBucketOrderRows = 64
+  val FlagNoBucketOrderRows = 128
 
   /** The int32 fields of `dpf_config`, in declaration order (checked against include/dpf.h by tests/test_jni_shim.py). */
   val ConfigIntFields: Array[String] = Array(

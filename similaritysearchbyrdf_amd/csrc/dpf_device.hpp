@@ -116,6 +116,9 @@ struct LeafScanParams {
     // kernel of one slice are both enqueued and the word the query conversion wrote picks one
     const int32_t *gate = nullptr;
     int32_t gate_want = 0;
+    // 1: base16 holds the rows in bucket order (row of id slot s at s * ks * 32 elements, beside ids[s]) instead of by id:
+    // a tile's rows are one contiguous run
+    int32_t rows_in_slot_order = 0;
 };
 
 struct RerankParams {
@@ -169,6 +172,9 @@ void launch_units(const uint32_t *lq_cnt, const int64_t *lq_off, const uint32_t 
 void launch_tile_maxnorm(uint4 *tiles, int64_t ntiles, const int32_t *ids, const float *norms, const float *errs, int64_t row_begin,
                          int64_t row_end, float *slot_norms, hipStream_t stream, const uint4 *tails = nullptr, uint4 *slot_tails = nullptr,
                          uint32_t *bounds = nullptr);
+// dst[s] = the fp16 row of ids[s] (zeros for ids outside [row_begin, row_end)): the rows once more, in bucket order
+void launch_rows_to_slot_order(const int32_t *ids, int64_t nslots, const uint16_t *base16, int row_elems, int64_t row_begin,
+                               int64_t row_end, uint16_t *dst, hipStream_t stream);
 int leafscan_f16_steps(int dim);
 int leafscan_f16_filter_dim(int dim, int metric);
 int leafscan_tile_rows(int ks);

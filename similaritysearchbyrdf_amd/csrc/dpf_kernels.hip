@@ -1973,7 +1973,9 @@ __device__ __forceinline__ void leafscan_body(const LeafScanParams &p, const uin
 #pragma unroll
                 for (int t = 0; t < KS; t++) xb[rb][t] = *(const f16x8 *)(row + 32 * t);
             } else {
-            const size_t at = (size_t)(id0[rb] >= 0 ? id0[rb] - row_lo : 0);
+            // by id, or (bucket-order copy) by the slot the id sits in; lanes past the tile's end re-read its last row
+            const size_t at = p.rows_in_slot_order ? (size_t)(tile_slot0 + min(rb * 16u + (uint32_t)i16, rows - 1u))
+                                                   : (size_t)(id0[rb] >= 0 ? id0[rb] - row_lo : 0);
             const uint16_t *row = B16 + at * STRIDE + 8 * g;
 #pragma unroll
             for (int t = 0; t < KS; t++) xb[rb][t] = *(const f16x8 *)(row + 32 * t);
@@ -2078,6 +2080,27 @@ static void launch_leafscan_f16_m(const LeafScanParams &p, hipStream_t stream)
         DPF_LB(32);
     }
 #undef DPF_LB
+}
+
+__global__ __launch_bounds__(256) void k_rows_to_slot_order(const int32_t *__restrict__ ids, int64_t nslots, const uint4 *__restrict__ base16,
+                                                            int pieces, int64_t row_begin, int64_t row_end, uint4 *__restrict__ dst)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nslots * pieces) return;
+    const int64_t s = i / pieces;
+    const int c = (int)(i - s * pieces);
+    const int64_t id = ids[s];
+    dst[i] = id >= row_begin && id < row_end ? base16[(id - row_begin) * pieces + c] : make_uint4(0u, 0u, 0u, 0u);
+}
+
+void launch_rows_to_slot_order(const int32_t *ids, int64_t nslots, const uint16_t *base16, int row_elems, int64_t row_begin,
+                               int64_t row_end, uint16_t *dst, hipStream_t stream)
+{
+    const int pieces = row_elems / 8;
+    const int64_t total = nslots * pieces;
+    if (total > 0)
+        hipLaunchKernelGGL(k_rows_to_slot_order, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, ids, nslots,
+                           (const uint4 *)base16, pieces, row_begin, row_end, (uint4 *)dst);
 }
 
 // k_refine: between two passes of the scan, tighten each query's threshold from what the first

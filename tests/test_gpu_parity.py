@@ -1388,3 +1388,26 @@ def test_streamed_fit_equals_whole_fit():
             assert np.array_equal(a, b)
         ix2.close()
         ix.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("metric,dim,kw", [("l2", 100, {}), ("dot", 100, {}), ("l2", 128, {}), ("l2", 33, {}), ("l2", 256, {}),
+                                           ("l2", 100, dict(row_begin=5000, row_end=14000)), ("l2", 100, dict(table_begin=1, table_end=4))])
+def test_bucket_order_rows_scan_equals_gather(metric, dim, kw):
+    # DPF_FLAG_BUCKET_ORDER_ROWS: the scan reads its fp16 rows from a second copy laid out in bucket order; same
+    # ids and scores as the per-query gather rerank, bit for bit (whole tiles, ragged last tiles, row and table shards,
+    # a second fit that rebuilds the copy)
+    params, X, Q, pick = make_problem(n=20000, nq=300, dim=dim, bucket_overflow=80, table_num=3, permutation_num=2, n_clusters=12)
+    fast = DpfIndex(dict(params, flags=64), metric=metric, **kw)
+    slow = DpfIndex(dict(params, flags=2), metric=metric, **kw)
+    qids = pick.astype(np.int32)
+    qids[:5] = [0, 5, 127, 128, -1]
+    for part in (X[:12000], X[12000:]):
+        fast.fit(part)
+        slow.fit(part)
+        for steps in (0, 1, 3):
+            fi, fs = fast.query_topk(qids, Q, steps=steps, k=10)
+            assert fast.stats()["last_path"] == 1
+            si, ss = slow.query_topk(qids, Q, steps=steps, k=10)
+            assert np.array_equal(fi, si)
+            assert np.array_equal(fs, ss, equal_nan=True)
