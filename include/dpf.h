@@ -155,6 +155,8 @@ typedef struct dpf_stats {
     int64_t base8_bytes;             /* HBM bytes of the int8 copy of the resident rows (0: the rows do not allow one)   */
     int64_t last_scan_int8;          /* 1: the last bucket-major batch was scanned in int8, 0: in fp16                    */
     int64_t bucket_order_bytes;      /* HBM bytes of the bucket-order copy of the fp16 rows (0: the scan gathers its rows by id) */
+    int64_t debug_bound_violations;  /* since dpf_create: indices outside their arrays met by the scan's loaders; only a build of
+                                        the library with -DDPF_DEBUG_BOUNDS looks (and clamps them); always 0 otherwise        */
 } dpf_stats;
 
 typedef struct dpf_index dpf_index;

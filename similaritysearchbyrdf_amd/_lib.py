@@ -40,7 +40,7 @@ class DpfStats(C.Structure):
         (n, C.c_int64) for n in ("last_overflowed", "last_sizes_carried", "total_topk_batches", "total_sized_on_host",
                                  "total_carried", "total_rerun", "total_overflowed", "total_gather_batches",
                                  "base16_bytes", "tile_rows", "num_tiles", "resident_ids", "hash_undecided_rows",
-                                 "base8_bytes", "last_scan_int8", "bucket_order_bytes")]
+                                 "base8_bytes", "last_scan_int8", "bucket_order_bytes", "debug_bound_violations")]
 
 
 EXPORTS = (

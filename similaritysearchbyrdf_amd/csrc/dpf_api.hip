@@ -167,7 +167,8 @@ struct dpf_index {
     std::vector<int32_t> w, chain_fn, part_w;
     DevBuf d_fnsT, d_b, d_w, d_chain, d_part_fns, d_part_b, d_part_w, d_fn_norm;
     DevBuf ws_proj_codes, ws_proj_norm, ws_proj_flag, ws_proj_rows;   // matrix-core projection (dpf_project.hip)
-    unsigned char *d_proj_counters = nullptr;                         // [0] undecided rows of the last call (u32), [8] running total (u64)
+    unsigned char *d_proj_counters = nullptr;                         // [0] undecided rows of the last call (u32), [8] running total (u64),
+                                                                      // [16] out-of-bounds indices counted by a -DDPF_DEBUG_BOUNDS build of the scan (u64)
     HashParams hp{};
 
     int64_t n = 0;
@@ -340,8 +341,8 @@ extern "C" int dpf_create(const dpf_config *cfg, dpf_index **out)
     if (e == hipSuccess) ix->scratch_ptr = (unsigned char *)scratch_of(cfg->device, &e);
     if (e == hipSuccess) e = hipMalloc((void **)&ix->d_short_hash, sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(ix->d_short_hash, 0, sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMalloc((void **)&ix->d_proj_counters, 16);
-    if (e == hipSuccess) e = hipMemset(ix->d_proj_counters, 0, 16);
+    if (e == hipSuccess) e = hipMalloc((void **)&ix->d_proj_counters, 32);
+    if (e == hipSuccess) e = hipMemset(ix->d_proj_counters, 0, 32);
     if (e == hipSuccess) e = hipHostMalloc((void **)&ix->pinned, 12 * sizeof(int64_t), hipHostMallocDefault);
     for (int i = 0; i < 6 && e == hipSuccess; i++) e = hipEventCreate(&ix->ev[i]);
     for (int i = 0; i < 6 && e == hipSuccess; i++) e = hipEventCreate(&ix->ev_scan[i]);
@@ -1499,6 +1500,9 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     lp.debug = 0;
     lp.Q16 = ix->ws_q16.as<uint16_t>(); lp.base16 = ix->d_base16.as<uint16_t>();
     if (ix->slot16_ok) { lp.base16 = ix->d_slot16.as<uint16_t>(); lp.rows_in_slot_order = 1; }
+    lp.dbg_slots = (int64_t)(ix->d_ids.cap / 4); lp.dbg_rows = std::max<int64_t>(ix->base_rows, 1); lp.dbg_nq = nq;
+    lp.dbg_pairs = (int64_t)(ix->ws_leaf_queries.cap / 4);
+    lp.dbg_violations = (unsigned long long *)(ix->d_proj_counters + 16);
     lp.slot_norm = ix->d_slot_norm.as<float>(); lp.qc = (const float4 *)ix->ws_qc.p;
     lp.units = (const uint4 *)ix->ws_units.p;
     lp.num_cus = ix->num_cus; lp.ks = ix->ks16;
@@ -2078,6 +2082,8 @@ extern "C" int dpf_get_stats(dpf_index *ix, dpf_stats *out)
         unsigned long long und = 0;
         HIPCHECK(ix, hipMemcpy(&und, ix->d_proj_counters + 8, 8, hipMemcpyDeviceToHost));
         ix->st.hash_undecided_rows = (int64_t)und;
+        HIPCHECK(ix, hipMemcpy(&und, ix->d_proj_counters + 16, 8, hipMemcpyDeviceToHost));
+        ix->st.debug_bound_violations = (int64_t)und;
     }
     int rc = last_totals(ix, &ix->st.last_raw_candidates, &ix->st.last_unique_candidates);
     if (rc != DPF_OK) return rc;

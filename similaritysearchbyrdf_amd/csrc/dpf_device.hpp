@@ -119,6 +119,10 @@ struct LeafScanParams {
     // 1: base16 holds the rows in bucket order (row of id slot s at s * ks * 32 elements, beside ids[s]) instead of by id:
     // a tile's rows are one contiguous run
     int32_t rows_in_slot_order = 0;
+    // what the index arithmetic of the tile and query loaders may reach (checked only by builds made with
+    // -DDPF_DEBUG_BOUNDS, which count every access outside into *dbg_violations and clamp it)
+    int64_t dbg_slots = 0, dbg_rows = 0, dbg_nq = 0, dbg_pairs = 0;
+    unsigned long long *dbg_violations = nullptr;
 };
 
 struct RerankParams {

@@ -1456,6 +1456,21 @@ void launch_tile_maxnorm(uint4 *tiles, int64_t ntiles, const int32_t *ids, const
     if (ntiles > 0) hipLaunchKernelGGL(k_tile_maxnorm, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, stream, tiles, ntiles, ids, norms, errs, row_begin, row_end, slot_norms, tails, slot_tails, bounds);
 }
 
+// Bounds instrumentation of the scan's loaders (builds made with -DDPF_DEBUG_BOUNDS only): an index outside what the
+// host says the arrays hold is counted and replaced by 0, so that a faulty index shows as a count, not as a memory fault.
+#ifdef DPF_DEBUG_BOUNDS
+template <typename I>
+__device__ __forceinline__ I dbg_bound(const LeafScanParams &p, I idx, int64_t limit)
+{
+    if ((unsigned long long)(long long)idx < (unsigned long long)limit) return idx;
+    atomicAdd(p.dbg_violations, 1ull);
+    return (I)0;
+}
+#define DPF_BOUND(p, idx, limit) dbg_bound(p, idx, limit)
+#else
+#define DPF_BOUND(p, idx, limit) (idx)
+#endif
+
 // Ablation switches of the scan (timing experiments that give wrong answers on purpose) exist only in
 // builds made with -DDPF_ABLATE=<bits> (1: loads and products only, 2: every query row from one hot spot,
 // 4: no in-tile tightening); the shipped kernel has none.
@@ -1572,7 +1587,7 @@ __device__ __forceinline__ void leafscan_chunks(const LeafScanParams &p, const u
     const float c32 = I8 ? 0.f : leafscan_c32(STRIDE);
     auto flush = [&](int n) {
         if (lane < n) {
-            const int32_t fq = s_fq[lane];
+            const int32_t fq = DPF_BOUND(p, s_fq[lane], p.dbg_nq);
             const int at = atomicAdd(&p.emit_cnt[fq], 1);
             if (at < p.emit_cap) {
                 p.emit[(size_t)fq * p.emit_cap + at] = s_fid[lane];
@@ -1584,14 +1599,14 @@ __device__ __forceinline__ void leafscan_chunks(const LeafScanParams &p, const u
     // (QLDS) the 16 query rows named by `qs` (lane i16 holds operand row i16's query) on their way into the wave's LDS block
     auto stage_queries = [&](int32_t qs) {
         const int32_t ql = __shfl(qs, lane >> 2);
-        const uint16_t *qr = Q16 + (size_t)(ql >= 0 ? ql : 0) * STRIDE + 8 * (lane & 3);
+        const uint16_t *qr = Q16 + DPF_BOUND(p, (size_t)(ql >= 0 ? ql : 0), p.dbg_nq) * STRIDE + 8 * (lane & 3);
 #pragma unroll
         for (int t = 0; t < KS; t++)
             __builtin_amdgcn_global_load_lds(qr + 32 * t, (__attribute__((address_space(3))) void *)(s_q + 64 * t), 16, 0, 0);
     };
     for (uint32_t c = 0; c < nq; c += 16u) {
         f16x8 qa[QS];
-        const size_t qat = (size_t)(qsc >= 0 ? qsc : 0);
+        const size_t qat = DPF_BOUND(p, (size_t)(qsc >= 0 ? qsc : 0), p.dbg_nq);
         const uint16_t *qrow = Q16 + (DPF_ABLATION(p, 2) ? (qat & 15) : qat) * STRIDE + 8 * g;   // debug 2: all query rows from one hot spot (timing only)
         if constexpr (QLDS) {
             if (c == 0) stage_queries(qsc);               // (later chunks: requested while the chunk before them was finishing)
@@ -1599,7 +1614,7 @@ __device__ __forceinline__ void leafscan_chunks(const LeafScanParams &p, const u
             // quad j reads the query at chunk position j; operand row i16 then holds position pi(i16) = jq
             const int lj = lane >> 2;
             const int32_t ql = __shfl(qsc, 4 * (lj & 3) + (lj >> 2));
-            const uint16_t *qr = Q16 + (size_t)(ql >= 0 ? ql : 0) * STRIDE + 8 * (lane & 3);
+            const uint16_t *qr = Q16 + DPF_BOUND(p, (size_t)(ql >= 0 ? ql : 0), p.dbg_nq) * STRIDE + 8 * (lane & 3);
             const int src4 = (((lane & 3) << 4) | (lane & 12) | (lane >> 4)) << 2;
             f16x8 raw[QS];
 #pragma unroll
@@ -1617,7 +1632,7 @@ __device__ __forceinline__ void leafscan_chunks(const LeafScanParams &p, const u
         const int32_t qcur = qsc;
         // query indices two chunks ahead
         qsc = qsn;
-        qsn = c + 32u + jq < nq ? p.leaf_queries[lq0 + c + 32u + jq] : -1;
+        qsn = c + 32u + jq < nq ? p.leaf_queries[DPF_BOUND(p, lq0 + c + 32u + jq, p.dbg_pairs)] : -1;
 
         // per-slot thresholds; lane i16 of every 16-lane group holds query slot i16
         {
@@ -1844,7 +1859,7 @@ __device__ __forceinline__ void leafscan_chunks(const LeafScanParams &p, const u
                     }
                     if (have && rank == p.k - 1) {
                         const float v = sqrtf(fmaxf(mine, 0.f) * 1.000001f) * 1.000001f + cxm;
-                        atomicMin(&p.tau[qq], enc_f32((v + 2.0f * sc.z) * 1.000002f));
+                        atomicMin(&p.tau[DPF_BOUND(p, qq, p.dbg_nq)], enc_f32((v + 2.0f * sc.z) * 1.000002f));
                     }
                 }
             }
@@ -1858,7 +1873,7 @@ __device__ __forceinline__ void leafscan_flush_rest(const LeafScanParams &p, con
 {
     const int lane = threadIdx.x & 63;
     if (lane < nbuf) {
-        const int32_t fq = s_fq[lane];
+        const int32_t fq = DPF_BOUND(p, s_fq[lane], p.dbg_nq);
         const int at = atomicAdd(&p.emit_cnt[fq], 1);
         if (at < p.emit_cap) {
             p.emit[(size_t)fq * p.emit_cap + at] = s_fid[lane];
@@ -1933,11 +1948,11 @@ __device__ __forceinline__ void leafscan_body(const LeafScanParams &p, const uin
 #pragma unroll
         for (int rb = 0; rb < RB; rb++) {
             const uint32_t idx = rb * 16 + i16;
-            int32_t v = idx < rows ? p.ids[U.x + idx] : -1;
+            int32_t v = idx < rows ? p.ids[DPF_BOUND(p, U.x + idx, p.dbg_slots)] : -1;
             if (!(v >= row_lo && v < row_hi)) v = -1;
             id[rb] = v;
         }
-        qs = jq < nq ? p.leaf_queries[U.z + jq] : -1;
+        qs = jq < nq ? p.leaf_queries[DPF_BOUND(p, U.z + jq, p.dbg_pairs)] : -1;
     };
 
     uint4 U0 = desc(u), U1 = desc(u_next);
@@ -1958,7 +1973,7 @@ __device__ __forceinline__ void leafscan_body(const LeafScanParams &p, const uin
             for (int rb = 0; rb < RB; rb++) {
                 if (rb * 16u >= rows && rb > 0) continue;
                 if (g == 0 && rb * 16u + (uint32_t)i16 < rows)
-                    __builtin_amdgcn_global_load_lds(p.slot_tail + tile_slot0 + rb * 16u + (uint32_t)i16,
+                    __builtin_amdgcn_global_load_lds(p.slot_tail + DPF_BOUND(p, tile_slot0 + rb * 16u + (uint32_t)i16, p.dbg_slots),
                                                      (__attribute__((address_space(3))) void *)(s_xt[wave] + rb * 16), 16, 0, 0);
             }
         }
@@ -1969,19 +1984,19 @@ __device__ __forceinline__ void leafscan_body(const LeafScanParams &p, const uin
                 // quad j reads row pi(j) of the block whole; the permutation leaves row i16 in operand column i16
                 const int lj = lane >> 2;
                 const int32_t idl = __shfl(id0[rb], 4 * (lj & 3) + (lj >> 2));
-                const uint16_t *row = B16 + (size_t)(idl >= 0 ? idl - row_lo : 0) * STRIDE + 8 * (lane & 3);
+                const uint16_t *row = B16 + DPF_BOUND(p, (size_t)(idl >= 0 ? idl - row_lo : 0), p.dbg_rows) * STRIDE + 8 * (lane & 3);
 #pragma unroll
                 for (int t = 0; t < KS; t++) xb[rb][t] = *(const f16x8 *)(row + 32 * t);
             } else {
             // by id, or (bucket-order copy) by the slot the id sits in; lanes past the tile's end re-read its last row
-            const size_t at = p.rows_in_slot_order ? (size_t)(tile_slot0 + min(rb * 16u + (uint32_t)i16, rows - 1u))
-                                                   : (size_t)(id0[rb] >= 0 ? id0[rb] - row_lo : 0);
+            const size_t at = p.rows_in_slot_order ? DPF_BOUND(p, (size_t)(tile_slot0 + min(rb * 16u + (uint32_t)i16, rows - 1u)), p.dbg_slots)
+                                                   : DPF_BOUND(p, (size_t)(id0[rb] >= 0 ? id0[rb] - row_lo : 0), p.dbg_rows);
             const uint16_t *row = B16 + at * STRIDE + 8 * g;
 #pragma unroll
             for (int t = 0; t < KS; t++) xb[rb][t] = *(const f16x8 *)(row + 32 * t);
             }
-            if constexpr (I8) nJ[rb] = rb * 16u + (uint32_t)i16 < rows ? p.slot_nj8[tile_slot0 + rb * 16u + (uint32_t)i16] : 0;
-            else nJ[rb] = rb * 16u + (uint32_t)i16 < rows ? p.slot_norm[tile_slot0 + rb * 16u + (uint32_t)i16] : 0.f;
+            if constexpr (I8) nJ[rb] = rb * 16u + (uint32_t)i16 < rows ? p.slot_nj8[DPF_BOUND(p, tile_slot0 + rb * 16u + (uint32_t)i16, p.dbg_slots)] : 0;
+            else nJ[rb] = rb * 16u + (uint32_t)i16 < rows ? p.slot_norm[DPF_BOUND(p, tile_slot0 + rb * 16u + (uint32_t)i16, p.dbg_slots)] : 0.f;
         }
         if constexpr (COAL) {
             const int src4 = (((lane & 3) << 4) | (lane & 12) | (lane >> 4)) << 2;
@@ -2005,7 +2020,7 @@ __device__ __forceinline__ void leafscan_body(const LeafScanParams &p, const uin
         const float cxm = __uint_as_float(U0.w << 16);            // upper bound of the largest |x - x~|
         // the next unit's ids and first query indices, the descriptor after it
         // the second chunk's query indices ride along with the rows
-        const int32_t qsc = qs0, qsn = 16u + jq < nq ? p.leaf_queries[lq0 + 16u + jq] : -1;
+        const int32_t qsc = qs0, qsn = 16u + jq < nq ? p.leaf_queries[DPF_BOUND(p, lq0 + 16u + jq, p.dbg_pairs)] : -1;
         U0 = U1;
         U1 = desc(u_after);
         u = u_next;
@@ -2407,7 +2422,10 @@ struct SeedRadiusParams {
 template <int KSQ>   // > 0: ks == KSQ, the query row stays in registers; 0: any ks, query pieces re-read (they stay in L1)
 __global__ __launch_bounds__(256) void k_seed_radius(SeedRadiusParams p, int64_t nq)
 {
-    constexpr int UR = 2;
+#ifndef SEED_UR
+#define SEED_UR 2
+#endif
+    constexpr int UR = SEED_UR;
     const int lane = threadIdx.x & 63;
     const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= nq) return;
