@@ -198,13 +198,32 @@ int dpf_hash_batch(dpf_index *ix, const void *Q, int64_t nq, int32_t *hashes, in
 
 /* DensevectorRDFInit.NewMultiThreadQueryBatch(queryArray, denseVectorArray, steps, _)
  * (Dense:335-360): per query the Set of similar ids as a sorted unique list,
- * restricted to [row_begin, row_end).  cand_offsets[nq+1] is caller memory;
- * *cand_ids comes from the library: normally the handle's own pinned host buffer, which the
- * handle's NEXT dpf_query_batch overwrites and dpf_destroy releases (copy what must outlive that;
- * the JNI shim copies into Java arrays at once); a malloc'd block when pinned memory cannot be had.
- * Either way pass it to dpf_free when done (a no-op for the handle's own buffer).  Host pointers. */
+ * restricted to [row_begin, row_end): query i's ids are cand_ids[cand_offsets[i] .. cand_offsets[i + 1]).
+ * cand_offsets[nq+1] is caller memory.  Host pointers.  Three ways to take the lists:
+ *   dpf_query_batch           *cand_ids is a malloc'd block the caller owns until dpf_free (the lists pass through a
+ *                             pinned staging area in pieces; a batch's Sets can be gigabytes - 2.9 GB for 10k queries
+ *                             over 30 trees of 1M rows - and fresh pageable memory takes them at a fraction of the link's rate);
+ *   dpf_query_batch_view      *cand_ids points into a pinned host buffer the HANDLE owns, grows and reuses: valid until the
+ *                             handle's next call that returns Sets, or dpf_destroy; for callers that copy the lists
+ *                             elsewhere at once (the JNI shim into a Java array); never passed to dpf_free;
+ *   dpf_query_batch_resident  the lists stay on the device, only cand_offsets (the Set sizes) comes back; dpf_sets_fetch
+ *                             then copies the lists of the queries [q0, q1) to out[cand_offsets[q1] - cand_offsets[q0]]
+ *                             and dpf_sets_topk reranks every query's resident Set (Dense:477-505) - what a caller that
+ *                             looks at few Sets, or only at their sizes and top-k, needs.  The resident Sets belong to the
+ *                             handle's last dpf_query_batch* call and are dropped by any other query, hash, rerank or fit call. */
 int dpf_query_batch(dpf_index *ix, const int32_t *qids, const void *Q, int64_t nq, int32_t steps,
                     int64_t *cand_offsets, int32_t **cand_ids);
+int dpf_query_batch_view(dpf_index *ix, const int32_t *qids, const void *Q, int64_t nq, int32_t steps,
+                         int64_t *cand_offsets, const int32_t **cand_ids);
+int dpf_query_batch_resident(dpf_index *ix, const int32_t *qids, const void *Q, int64_t nq, int32_t steps,
+                             int64_t *cand_offsets);
+int dpf_sets_fetch(dpf_index *ix, int64_t q0, int64_t q1, int32_t *out);
+/* queries of the resident batch / ids in the resident Sets of the queries [q0, q1); -1 when there are no resident Sets
+ * (or the range is outside the batch): lets a binding check its buffer sizes against the library's own offsets */
+int64_t dpf_sets_queries(const dpf_index *ix);
+int64_t dpf_sets_count(const dpf_index *ix, int64_t q0, int64_t q1);
+int dpf_sets_topk(dpf_index *ix, int32_t k, int32_t *ids, double *scores);
+/* releases a block dpf_query_batch returned */
 void dpf_free(void *p);
 
 /* The query + rerank of DensevectorRDFInit.topKAndPrecisionScore (Dense:472-507)

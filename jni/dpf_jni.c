@@ -294,24 +294,102 @@ JNIEXPORT jintArray JNICALL Java_mclab_gpu_Dpf_queryBatch(JNIEnv *env, jclass cl
         free(po);
         return NULL;
     }
-    int32_t *ids = NULL;
-    int rc = dpf_query_batch(ix, (const int32_t *)pq, pv, (int64_t)nq, (int32_t)steps, po, &ids);
+    const int32_t *ids = NULL;                            /* the handle's own pinned buffer: copied into the Java array below */
+    int rc = dpf_query_batch_view(ix, (const int32_t *)pq, pv, (int64_t)nq, (int32_t)steps, po, &ids);
     (*env)->ReleaseDoubleArrayElements(env, q, pv, JNI_ABORT);
     if (pq) (*env)->ReleaseIntArrayElements(env, qids, pq, JNI_ABORT);
     const int64_t total = rc == DPF_OK ? po[nq] : 0;
     if (rc == DPF_OK || rc == DPF_ENOTFIT) (*env)->SetLongArrayRegion(env, offsets, 0, (jsize)(nq + 1), (const jlong *)po);
     free(po);
-    if (rc != DPF_OK) { dpf_free(ids); throw_dpf(env, ix, rc); return NULL; }
+    if (rc != DPF_OK) { throw_dpf(env, ix, rc); return NULL; }
     if (total > INT_MAX) {
-        dpf_free(ids);
         jclass ex = (*env)->FindClass(env, "java/lang/IllegalStateException");
         if (ex) (*env)->ThrowNew(env, ex, "Dpf.queryBatch: the batch's candidate lists exceed a Java array (2^31 - 1 ids): use fewer queries per call");
         return NULL;
     }
     jintArray out = (*env)->NewIntArray(env, (jsize)total);
     if (out && total > 0) (*env)->SetIntArrayRegion(env, out, 0, (jsize)total, (const jint *)ids);
-    dpf_free(ids);
     return out;
+}
+
+/* queryBatchResident(h, qids[nq] or null, q[nq*dim] doubles, nq, steps, offsets[nq+1]): the Sets stay on the device, only
+ * their sizes come back (offsets); setsFetch / setsTopK read them until the handle's next query, hash, rerank or fit call */
+JNIEXPORT void JNICALL Java_mclab_gpu_Dpf_queryBatchResident(JNIEnv *env, jclass cls, jlong h, jintArray qids, jdoubleArray q,
+                                                             jlong nq, jint steps, jlongArray offsets)
+{
+    (void)cls;
+    dpf_index *ix = handle_of(h);
+    dpf_config c;
+    if (!config_of(env, ix, &c) || !doubles_handle(env, &c, nq)) return;
+    if (!long_enough(env, qids, nq, 1, "Dpf.queryBatchResident: qids must hold nq ints") ||
+        !long_enough(env, q, (int64_t)nq * c.dim, 0, "Dpf.queryBatchResident: q must hold nq * dim doubles") ||
+        !long_enough(env, offsets, (int64_t)nq + 1, 0, "Dpf.queryBatchResident: offsets must hold nq + 1 longs"))
+        return;
+    int64_t *po = (int64_t *)malloc(((size_t)nq + 1) * 8);
+    if (!po) { throw_oom(env, "Dpf.queryBatchResident: native offsets"); return; }
+    jint *pq = qids ? (*env)->GetIntArrayElements(env, qids, NULL) : NULL;
+    jdouble *pv = (!qids || pq) ? (*env)->GetDoubleArrayElements(env, q, NULL) : NULL;
+    if (!pv) {
+        if (pq) (*env)->ReleaseIntArrayElements(env, qids, pq, JNI_ABORT);
+        free(po);
+        return;
+    }
+    int rc = dpf_query_batch_resident(ix, (const int32_t *)pq, pv, (int64_t)nq, (int32_t)steps, po);
+    (*env)->ReleaseDoubleArrayElements(env, q, pv, JNI_ABORT);
+    if (pq) (*env)->ReleaseIntArrayElements(env, qids, pq, JNI_ABORT);
+    if (rc == DPF_OK || rc == DPF_ENOTFIT) (*env)->SetLongArrayRegion(env, offsets, 0, (jsize)(nq + 1), (const jlong *)po);
+    free(po);
+    throw_dpf(env, ix, rc);
+}
+
+/* setsFetch(h, q0, q1, count) -> the ids of the resident Sets of the queries [q0, q1), back to back; count = offsets(q1) -
+ * offsets(q0) as queryBatchResident returned them */
+JNIEXPORT jintArray JNICALL Java_mclab_gpu_Dpf_setsFetch(JNIEnv *env, jclass cls, jlong h, jlong q0, jlong q1, jlong count)
+{
+    (void)cls;
+    dpf_index *ix = handle_of(h);
+    if (!ix) { throw_iae(env, "Dpf: null handle"); return NULL; }
+    if (count < 0 || count > INT_MAX) { throw_iae(env, "Dpf.setsFetch: count does not fit a Java array (fetch fewer queries at a time)"); return NULL; }
+    int32_t *buf = (int32_t *)malloc((size_t)(count > 0 ? count : 1) * 4);
+    if (!buf) { throw_oom(env, "Dpf.setsFetch: native buffer"); return NULL; }
+    /* the library copies offsets(q1) - offsets(q0) ids: refuse a count that disagrees with its own offsets */
+    int rc = dpf_sets_count(ix, (int64_t)q0, (int64_t)q1) == (int64_t)count ? dpf_sets_fetch(ix, (int64_t)q0, (int64_t)q1, buf) : DPF_EINVAL;
+    if (rc != DPF_OK) {
+        free(buf);
+        if (dpf_sets_count(ix, (int64_t)q0, (int64_t)q1) != (int64_t)count) throw_iae(env, "Dpf.setsFetch: count is not offsets(q1) - offsets(q0) of the resident Sets");
+        else throw_dpf(env, ix, rc);
+        return NULL;
+    }
+    jintArray out = (*env)->NewIntArray(env, (jsize)count);
+    if (out && count > 0) (*env)->SetIntArrayRegion(env, out, 0, (jsize)count, (const jint *)buf);
+    free(buf);
+    return out;
+}
+
+/* setsTopK(h, nq, k, ids[nq*k], scores[nq*k]): the rerank of DensevectorRDFInit.scala:477-505 on the resident Sets */
+JNIEXPORT void JNICALL Java_mclab_gpu_Dpf_setsTopK(JNIEnv *env, jclass cls, jlong h, jlong nq, jint k, jintArray ids, jdoubleArray scores)
+{
+    (void)cls;
+    dpf_index *ix = handle_of(h);
+    if (!ix) { throw_iae(env, "Dpf: null handle"); return; }
+    const int64_t cells = (int64_t)nq * k;
+    if (nq < 0 || k < 1 || k > 64 || cells > INT_MAX || dpf_sets_count(ix, 0, 0) < 0 || dpf_sets_queries(ix) != (int64_t)nq) {
+        throw_iae(env, "Dpf.setsTopK: nq must be the resident batch's query count, k in [1, 64]");
+        return;
+    }
+    if (!long_enough(env, ids, cells, 0, "Dpf.setsTopK: ids must hold nq * k ints") ||
+        !long_enough(env, scores, cells, 0, "Dpf.setsTopK: scores must hold nq * k doubles"))
+        return;
+    int32_t *oi = (int32_t *)malloc((size_t)(cells > 0 ? cells : 1) * 4);
+    double *os = (double *)malloc((size_t)(cells > 0 ? cells : 1) * 8);
+    if (!oi || !os) { free(oi); free(os); throw_oom(env, "Dpf.setsTopK: native result buffers"); return; }
+    int rc = dpf_sets_topk(ix, (int32_t)k, oi, os);
+    if (rc == DPF_OK && cells > 0) {
+        (*env)->SetIntArrayRegion(env, ids, 0, (jsize)cells, (const jint *)oi);
+        (*env)->SetDoubleArrayRegion(env, scores, 0, (jsize)cells, os);
+    }
+    free(oi); free(os);
+    throw_dpf(env, ix, rc);
 }
 
 /* queryTopK(h, qids[nq] or null, q[nq*dim] doubles, nq, steps, k, ids[nq*k], scores[nq*k]): ids -1 / scores NaN padded */

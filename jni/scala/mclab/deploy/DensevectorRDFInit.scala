@@ -149,6 +149,36 @@ private[mclab] object DensevectorRDFInit {
     Array.tabulate(n)(i => ids.slice(offsets(i).toInt, offsets(i + 1).toInt).map(x => Int.box(x): AnyRef).toSet)
   }
 
+  /** NewMultiThreadQueryBatch without moving the Sets: they stay on the device.  Returns their sizes; fetchSets then
+    * brings over the Sets of a range of the batch's queries, topKOfResidentSets reranks all of them (the order of
+    * topKAndPrecisionScore).  A batch's Sets can be gigabytes of ids, which a caller that looks at a few of them, or only
+    * at the top-k, never needs on the JVM heap.  Valid until the next query / fit call on this object. */
+  def queryBatchSizes(queryArray: Array[Int], denseVectorArray: Array[DenseVector], steps: Int = 0): Array[Long] = {
+    val n = queryArray.length
+    residentOffsets = new Array[Long](n + 1)
+    if (gpu == 0L) { println("need to fit the data first"); return new Array[Long](n) }
+    try Dpf.queryBatchResident(gpu, queryArray, flatQueries(denseVectorArray, n), n, steps, residentOffsets)
+    catch { case _: NullPointerException => println("need to fit the data first"); java.util.Arrays.fill(residentOffsets, 0L) }
+    Array.tabulate(n)(i => residentOffsets(i + 1) - residentOffsets(i))
+  }
+
+  def fetchSets(q0: Int, q1: Int): Array[Set[AnyRef]] = {
+    val base = residentOffsets(q0)
+    val ids = Dpf.setsFetch(gpu, q0, q1, residentOffsets(q1) - base)
+    Array.tabulate(q1 - q0)(i => ids.slice((residentOffsets(q0 + i) - base).toInt, (residentOffsets(q0 + i + 1) - base).toInt)
+      .map(x => Int.box(x): AnyRef).toSet)
+  }
+
+  def topKOfResidentSets(k: Int): (Array[Array[Int]], Array[Array[Double]]) = {
+    val n = residentOffsets.length - 1
+    val ids = new Array[Int](n * k)
+    val scores = new Array[Double](n * k)
+    Dpf.setsTopK(gpu, n, k, ids, scores)
+    (Array.tabulate(n)(i => ids.slice(i * k, (i + 1) * k).filter(_ >= 0)), Array.tabulate(n)(i => scores.slice(i * k, (i + 1) * k)))
+  }
+
+  private var residentOffsets: Array[Long] = Array(0L)
+
   def NewMultiThreadQueryBatch(queryArray: Array[Int], denseVectorArray: Array[DenseVector], steps: Int = 0,
                                queryThreadNum: Int = 5): Array[Set[AnyRef]] = sets(queryArray, denseVectorArray, steps)
 

@@ -70,6 +70,12 @@ object Dpf {
   @native def fitFloat(h: Long, rows: Array[Float], n: Long): Unit
   @native def hashBatch(h: Long, q: Array[Double], nq: Long, hashes: Array[Int], parts: Array[Int]): Unit
   @native def queryBatch(h: Long, qids: Array[Int], q: Array[Double], nq: Long, steps: Int, offsets: Array[Long]): Array[Int]
+  /** the Sets stay on the device; offsets (nq + 1) receives their sizes as a running sum */
+  @native def queryBatchResident(h: Long, qids: Array[Int], q: Array[Double], nq: Long, steps: Int, offsets: Array[Long]): Unit
+  /** ids of the resident Sets of the queries [q0, q1); count = offsets(q1) - offsets(q0) */
+  @native def setsFetch(h: Long, q0: Long, q1: Long, count: Long): Array[Int]
+  /** top-k rerank (DensevectorRDFInit.topKAndPrecisionScore's order) of every resident Set */
+  @native def setsTopK(h: Long, nq: Long, k: Int, ids: Array[Int], scores: Array[Double]): Unit
   @native def queryTopK(h: Long, qids: Array[Int], q: Array[Double], nq: Long, steps: Int, k: Int, ids: Array[Int], scores: Array[Double]): Unit
   @native def rerank(h: Long, q: Array[Double], nq: Long, candOffsets: Array[Long], candIds: Array[Int], k: Int, ids: Array[Int], scores: Array[Double]): Unit
   @native def subindexDistribution(h: Long, out: Array[Double]): Unit

@@ -50,6 +50,8 @@ EXPORTS = (
     "dpf_subindex_distribution", "dpf_get_stats", "dpf_last_rerank_profile", "dpf_set_profiling",
     "dpf_save", "dpf_load", "dpf_get_config", "dpf_snapshot_sizes", "dpf_snapshot_copy", "dpf_set_option", "dpf_query_topk_device_static",
     "dpf_load_shard", "dpf_set_probe_mode", "dpf_host_alloc", "dpf_host_free", "dpf_last_incidences",
+    "dpf_query_batch_view", "dpf_query_batch_resident", "dpf_sets_fetch", "dpf_sets_topk",
+    "dpf_sets_queries", "dpf_sets_count",
 )
 
 # dpf_set_option keys (include/dpf.h)
@@ -94,6 +96,18 @@ def lib():
     L.dpf_hash_batch.argtypes = [vp, vp, C.c_int64, ip, ip]
     L.dpf_query_batch.restype = C.c_int
     L.dpf_query_batch.argtypes = [vp, ip, vp, C.c_int64, C.c_int32, i64p, C.POINTER(ip)]
+    L.dpf_query_batch_view.restype = C.c_int
+    L.dpf_query_batch_view.argtypes = [vp, ip, vp, C.c_int64, C.c_int32, i64p, C.POINTER(ip)]
+    L.dpf_query_batch_resident.restype = C.c_int
+    L.dpf_query_batch_resident.argtypes = [vp, ip, vp, C.c_int64, C.c_int32, i64p]
+    L.dpf_sets_fetch.restype = C.c_int
+    L.dpf_sets_fetch.argtypes = [vp, C.c_int64, C.c_int64, ip]
+    L.dpf_sets_queries.restype = C.c_int64
+    L.dpf_sets_queries.argtypes = [vp]
+    L.dpf_sets_count.restype = C.c_int64
+    L.dpf_sets_count.argtypes = [vp, C.c_int64, C.c_int64]
+    L.dpf_sets_topk.restype = C.c_int
+    L.dpf_sets_topk.argtypes = [vp, C.c_int32, ip, dp]
     L.dpf_free.restype = None
     L.dpf_free.argtypes = [vp]
     L.dpf_query_topk.restype = C.c_int
@@ -171,6 +185,18 @@ def pinned_array(shape, dtype):
     buf = (C.c_char * block.nbytes).from_address(block.ptr.value)
     buf._owner = block                         # a from_address buffer does not own its memory: the array keeps buf, buf the block
     return np.frombuffer(buf, dtype=dtype, count=n).reshape(shape)
+
+
+class _HandleView(np.ndarray):
+    """A numpy view of memory a handle owns: holds a reference to the handle so that it is not destroyed under the view."""
+
+    def __new__(cls, arr, owner):
+        obj = np.asarray(arr).view(cls)
+        obj._owner = owner
+        return obj
+
+    def __array_finalize__(self, obj):
+        self._owner = getattr(obj, "_owner", None)
 
 
 def _dp(a):
@@ -305,21 +331,49 @@ class DpfIndex:
         return h, p
 
     def query_batch(self, qids, Q, steps=0, copy=True):
-        """NewMultiThreadQueryBatch -> (offsets [nq+1] int64, ids int32).  copy=False returns the ids as a view of the
-        handle's own result buffer: valid until the handle's next query_batch (or close)."""
+        """NewMultiThreadQueryBatch -> (offsets [nq+1] int64, ids int32).  copy=True: through dpf_query_batch (a block of
+        the caller's own).  copy=False: dpf_query_batch_view - the ids are a view of the handle's pinned result buffer,
+        valid until the handle's next call that returns Sets (the array keeps the handle alive, not the contents)."""
         Q = self._rows(Q)
         nq = Q.shape[0]
         qids = _i32(qids)
         offsets = np.zeros(nq + 1, dtype=np.int64)
         pids = C.POINTER(C.c_int32)()
-        self._check(self.L_.dpf_query_batch(self.h, _ip(qids), Q.ctypes.data, nq, steps,
-                                            offsets.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(pids)))
+        fn = self.L_.dpf_query_batch if copy else self.L_.dpf_query_batch_view
+        self._check(fn(self.h, _ip(qids), Q.ctypes.data, nq, steps, offsets.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(pids)))
         total = int(offsets[nq])
         ids = np.ctypeslib.as_array(pids, shape=(max(total, 1),))[:total]
         if copy:
             ids = ids.copy()
-        self.L_.dpf_free(pids)
+            self.L_.dpf_free(pids)
+        else:
+            ids = _HandleView(ids, self)
         return offsets, ids
+
+    def query_batch_resident(self, qids, Q, steps=0):
+        """The Sets stay on the device; -> offsets [nq+1] (the Set sizes).  sets_fetch / sets_topk read them."""
+        Q = self._rows(Q)
+        nq = Q.shape[0]
+        offsets = np.zeros(nq + 1, dtype=np.int64)
+        self._check(self.L_.dpf_query_batch_resident(self.h, _ip(_i32(qids)), Q.ctypes.data, nq, steps,
+                                                     offsets.ctypes.data_as(C.POINTER(C.c_int64))))
+        self._resident_offsets = offsets
+        return offsets
+
+    def sets_fetch(self, q0, q1):
+        """The sorted unique id lists of the queries [q0, q1) of the resident Sets, back to back."""
+        off = self._resident_offsets
+        out = np.empty(max(int(off[q1] - off[q0]), 1), dtype=np.int32)
+        self._check(self.L_.dpf_sets_fetch(self.h, q0, q1, _ip(out)))
+        return out[:int(off[q1] - off[q0])]
+
+    def sets_topk(self, k=None):
+        nq = len(self._resident_offsets) - 1
+        k = k or self.top_k
+        ids = np.empty((nq, k), dtype=np.int32)
+        sc = np.empty((nq, k), dtype=np.float64)
+        self._check(self.L_.dpf_sets_topk(self.h, k, _ip(ids), _dp(sc)))
+        return ids, sc
 
     def query_topk(self, qids, Q, steps=0, k=None, out=None):
         """out = (ids [nq, k] int32, scores [nq, k] float64) to have the results written into given arrays

@@ -63,10 +63,6 @@ struct ScratchDev {
 };
 ScratchDev g_scratch[SCRATCH_MAX_DEVICES];
 std::mutex g_scratch_mutex;
-// result buffers of dpf_query_batch that belong to a handle (pinned host memory, reused from call to call): dpf_free
-// leaves these alone
-std::mutex g_results_mutex;
-std::vector<void *> g_handle_results;
 
 }  // namespace
 
@@ -229,13 +225,17 @@ struct dpf_index {
     int64_t prev_units = -1;                 // work units of the handle's last bucket-major batch (-1: none yet)
     unsigned long long *d_short_hash = nullptr;
     int64_t *pinned = nullptr;                        // host-pinned scratch (12 x int64)
-    int32_t *h_sets = nullptr;                        // dpf_query_batch's result lists: pinned host memory, grown as needed
+    int32_t *h_sets = nullptr;                        // dpf_query_batch_view's result lists: pinned host memory, grown as needed
     size_t h_sets_cap = 0;
     DevBuf ws_compact;                                // the same lists packed back to back on the device
+    bool sets_valid = false;                          // ws_compact / ws_misc / the padded query rows hold the Sets of dpf_query_batch_resident
+    std::vector<int64_t> sets_off;                    // their offsets
+    const void *sets_qpad = nullptr;                  // their padded query rows (ws_hq or ws_qpad)
     bool sizes_carried = false;                       // a bucket-major batch has sized leaf_queries[] / units[] already
     hipEvent_t ev[6]{};
     hipStream_t side_stream = nullptr;                // the list-building chain of a batch runs here, beside the first radii
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_stage[2] = {nullptr, nullptr};      // the two halves of h_stage when results leave through it in pieces
     int last_path = 0;
     bool profiling = false;
     bool last_timed = false;                          // the last top-k batch recorded its events
@@ -349,6 +349,7 @@ extern "C" int dpf_create(const dpf_config *cfg, dpf_index **out)
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ix->side_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ix->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ix->ev_join, hipEventDisableTiming);
+    for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipEventCreateWithFlags(&ix->ev_stage[i], hipEventDisableTiming);
     if (e != hipSuccess) {
         std::string m = std::string("dpf_create: ") + hipGetErrorString(e);
         delete ix;
@@ -388,19 +389,13 @@ extern "C" void dpf_destroy(dpf_index *ix)
     { DevBuf *pb[] = {&ix->d_fn_norm, &ix->ws_proj_codes, &ix->ws_proj_norm, &ix->ws_proj_flag, &ix->ws_proj_rows}; for (DevBuf *b : pb) b->release(); }
     if (ix->pinned) (void)hipHostFree(ix->pinned);
     ix->h_stage.release();
-    if (ix->h_sets) {
-        {
-            std::lock_guard<std::mutex> lock(g_results_mutex);
-            for (size_t i = 0; i < g_handle_results.size(); i++)
-                if (g_handle_results[i] == ix->h_sets) { g_handle_results.erase(g_handle_results.begin() + i); break; }
-        }
-        (void)hipHostFree(ix->h_sets);
-    }
+    if (ix->h_sets) (void)hipHostFree(ix->h_sets);
     ix->ws_compact.release();
     for (int i = 0; i < 6; i++) if (ix->ev[i]) (void)hipEventDestroy(ix->ev[i]);
     for (int i = 0; i < 6; i++) if (ix->ev_scan[i]) (void)hipEventDestroy(ix->ev_scan[i]);
     if (ix->ev_fork) (void)hipEventDestroy(ix->ev_fork);
     if (ix->ev_join) (void)hipEventDestroy(ix->ev_join);
+    for (int i = 0; i < 2; i++) if (ix->ev_stage[i]) (void)hipEventDestroy(ix->ev_stage[i]);
     if (ix->side_stream) (void)hipStreamDestroy(ix->side_stream);
     DevBuf *more[] = {&ix->ws_emit_ucnt, &ix->ws_emit_v, &ix->ws_leaf_units, &ix->ws_unit_off, &ix->ws_q_leaves, &ix->ws_q_leaf_cnt, &ix->d_leaf_tile0, &ix->ws_units, &ix->d_tiles, &ix->ws_lq_off, &ix->ws_lq_cursor, &ix->ws_leaf_queries,
                       &ix->ws_seed_cand, &ix->ws_seed_cnt, &ix->ws_seed_ids, &ix->ws_seed_scores, &ix->ws_emit, &ix->ws_emit_cnt,
@@ -853,6 +848,7 @@ extern "C" int dpf_fit(dpf_index *ix, const void *X, int64_t n)
     if (rc != DPF_OK) return rc;
     if (n < 0 || (n > 0 && !X)) return fail(ix, DPF_EINVAL, "dpf_fit: bad arguments");
     if (ix->cfg.flags & DPF_FLAG_HASH_ONLY) return fail(ix, DPF_EINVAL, "dpf_fit: this handle was created hash-only");
+    ix->sets_valid = false;
     const dpf_config &c = ix->cfg;
     const int L = c.num_tables, d = c.dim;
     const int64_t first = ix->n, total = first + n;
@@ -1648,6 +1644,7 @@ extern "C" int dpf_query_topk_device(dpf_index *ix, const int32_t *d_qids, const
     if (nq == 0) return DPF_OK;
     hipStream_t stream = (hipStream_t)stream_;
     HIPCHECK(ix, hipSetDevice(ix->cfg.device));
+    ix->sets_valid = false;
     const void *qpad; int64_t qstride;
     // the rerank kernels read whole 16-byte pieces, so they always get padded rows
     if ((rc = pad_queries(ix, d_Q, nq, stream, &qpad, &qstride)) != DPF_OK) return rc;
@@ -1822,6 +1819,7 @@ extern "C" int dpf_hash_batch(dpf_index *ix, const void *Q, int64_t nq, int32_t 
     if (rc != DPF_OK) return rc;
     if (nq < 0 || (nq > 0 && (!Q || !hashes))) return fail(ix, DPF_EINVAL, "dpf_hash_batch: bad arguments");
     if (nq == 0) return DPF_OK;
+    ix->sets_valid = false;
     HIPCHECK(ix, hipSetDevice(ix->cfg.device));
     const int L = ix->cfg.num_tables;
     const size_t qbytes = (size_t)nq * ix->cfg.dim * ix->elem;
@@ -1837,11 +1835,50 @@ extern "C" int dpf_hash_batch(dpf_index *ix, const void *Q, int64_t nq, int32_t 
     return DPF_OK;
 }
 
-extern "C" int dpf_query_batch(dpf_index *ix, const int32_t *qids, const void *Q, int64_t nq, int32_t steps,
-                               int64_t *cand_offsets, int32_t **cand_ids)
+// The Sets of a batch, left on the device: run_probe's per-query lists packed back to back in ws_compact, their
+// offsets in ws_misc (device) and sets_off (host), the padded query rows in ws_hq / ws_qpad.  Any later call that
+// reuses those workspaces clears sets_valid.
+static int sets_to_device(dpf_index *ix, const int32_t *qids, const void *Q, int64_t nq, int32_t steps, int64_t *cand_offsets)
 {
-    if (!ix) return DPF_EINVAL;
-    if (cand_ids) *cand_ids = nullptr;
+    ix->sets_valid = false;
+    cand_offsets[0] = 0;
+    HIPCHECK(ix, hipSetDevice(ix->cfg.device));
+    const size_t qbytes = (size_t)nq * ix->cfg.dim * ix->elem;
+    const size_t at_ids = (qbytes + 255) & ~(size_t)255;
+    HIPCHECK(ix, ix->h_stage.ensure(at_ids + (size_t)nq * 4 + 256));
+    HIPCHECK(ix, ix->ws_hq.ensure(qbytes));
+    int rc;
+    if ((rc = stage_to_device(ix, ix->ws_hq.p, Q, qbytes, 0, nullptr)) != DPF_OK) return rc;
+    const int32_t *dq = nullptr;
+    if (qids) {
+        HIPCHECK(ix, ix->ws_hqids.ensure((size_t)nq * 4));
+        if ((rc = stage_to_device(ix, ix->ws_hqids.p, qids, (size_t)nq * 4, at_ids, nullptr)) != DPF_OK) return rc;
+        dq = ix->ws_hqids.as<int32_t>();
+    }
+    // (the rerank kernels read whole 16-byte pieces: the Sets keep padded query rows for dpf_sets_topk)
+    const void *qpad; int64_t qstride;
+    if ((rc = pad_queries(ix, ix->ws_hq.p, nq, nullptr, &qpad, &qstride)) != DPF_OK) return rc;
+    if ((rc = run_probe(ix, dq, qpad, qstride, nq, steps, nullptr)) != DPF_OK) return rc;
+    // compact the per-query sets into one CSR array
+    HIPCHECK(ix, ix->ws_misc.ensure((size_t)(nq + 1) * 8));
+    launch_scan_i32(ix->ws_cnt.as<int32_t>(), nq, ix->ws_misc.as<int64_t>(), nullptr);
+    HIPCHECK(ix, hipMemcpy(cand_offsets, ix->ws_misc.p, (size_t)(nq + 1) * 8, hipMemcpyDeviceToHost));
+    const int64_t total = cand_offsets[nq];
+    if (total > 0) {
+        HIPCHECK(ix, ix->ws_compact.ensure((size_t)total * 4));
+        launch_compact(ix->ws_arena.as<int32_t>(), ix->ws_off.as<int64_t>(), ix->ws_cnt.as<int32_t>(), ix->ws_misc.as<int64_t>(),
+                       ix->ws_compact.as<int32_t>(), nq, nullptr);
+        HIPCHECK(ix, hipGetLastError());
+    }
+    ix->sets_off.assign(cand_offsets, cand_offsets + nq + 1);
+    ix->sets_qpad = qpad;
+    ix->sets_valid = true;
+    return DPF_OK;
+}
+
+static int sets_entry_checks(dpf_index *ix, const void *Q, int64_t nq, int32_t steps, int64_t *cand_offsets, const char *who, bool *empty)
+{
+    *empty = false;
     int rc = check_ready(ix, true);
     if (rc == DPF_ENOTFIT && cand_offsets && nq >= 0) {
         // Dense:422-424: an unfitted index yields empty sets
@@ -1849,72 +1886,138 @@ extern "C" int dpf_query_batch(dpf_index *ix, const int32_t *qids, const void *Q
         return rc;
     }
     if (rc != DPF_OK) return rc;
-    if (nq < 0 || steps < 0 || !cand_offsets || !cand_ids || (nq > 0 && !Q)) return fail(ix, DPF_EINVAL, "dpf_query_batch: bad arguments");
+    if (nq < 0 || steps < 0 || !cand_offsets || (nq > 0 && !Q)) return fail(ix, DPF_EINVAL, std::string(who) + ": bad arguments");
     cand_offsets[0] = 0;
-    if (nq == 0) { *cand_ids = (int32_t *)malloc(4); return DPF_OK; }
+    *empty = nq == 0;
+    return DPF_OK;
+}
+
+extern "C" int dpf_query_batch_resident(dpf_index *ix, const int32_t *qids, const void *Q, int64_t nq, int32_t steps,
+                                        int64_t *cand_offsets)
+{
+    if (!ix) return DPF_EINVAL;
+    bool empty;
+    int rc = sets_entry_checks(ix, Q, nq, steps, cand_offsets, "dpf_query_batch_resident", &empty);
+    if (rc != DPF_OK) return rc;
+    if (empty) { ix->sets_off.assign(1, 0); ix->sets_valid = true; return DPF_OK; }
+    return sets_to_device(ix, qids, Q, nq, steps, cand_offsets);
+}
+
+extern "C" int dpf_sets_fetch(dpf_index *ix, int64_t q0, int64_t q1, int32_t *out)
+{
+    if (!ix) return DPF_EINVAL;
+    if (!ix->sets_valid) return fail(ix, DPF_EINVAL, "dpf_sets_fetch: no resident Sets (dpf_query_batch_resident first; any other query or fit call drops them)");
+    const int64_t nq = (int64_t)ix->sets_off.size() - 1;
+    if (q0 < 0 || q1 < q0 || q1 > nq) return fail(ix, DPF_EINVAL, "dpf_sets_fetch: query range outside the batch");
+    const int64_t a = ix->sets_off[(size_t)q0], b = ix->sets_off[(size_t)q1];
+    if (b == a) return DPF_OK;
+    if (!out) return fail(ix, DPF_EINVAL, "dpf_sets_fetch: null output");
     HIPCHECK(ix, hipSetDevice(ix->cfg.device));
-    const size_t qbytes = (size_t)nq * ix->cfg.dim * ix->elem;
-    HIPCHECK(ix, ix->ws_hq.ensure(qbytes));
-    HIPCHECK(ix, hipMemcpy(ix->ws_hq.p, Q, qbytes, hipMemcpyHostToDevice));
-    const int32_t *dq = nullptr;
-    if (qids) {
-        HIPCHECK(ix, ix->ws_hqids.ensure((size_t)nq * 4));
-        HIPCHECK(ix, hipMemcpy(ix->ws_hqids.p, qids, (size_t)nq * 4, hipMemcpyHostToDevice));
-        dq = ix->ws_hqids.as<int32_t>();
-    }
-    if ((rc = run_probe(ix, dq, ix->ws_hq.p, ix->cfg.dim, nq, steps, nullptr)) != DPF_OK) return rc;
-    // compact the per-query sets into one CSR array
-    HIPCHECK(ix, ix->ws_misc.ensure((size_t)(nq + 1) * 8));
-    launch_scan_i32(ix->ws_cnt.as<int32_t>(), nq, ix->ws_misc.as<int64_t>(), nullptr);
-    HIPCHECK(ix, hipMemcpy(cand_offsets, ix->ws_misc.p, (size_t)(nq + 1) * 8, hipMemcpyDeviceToHost));
+    HIPCHECK(ix, hipMemcpy(out, ix->ws_compact.as<int32_t>() + a, (size_t)(b - a) * 4, hipMemcpyDeviceToHost));
+    return DPF_OK;
+}
+
+extern "C" int64_t dpf_sets_queries(const dpf_index *ix)
+{
+    return ix && ix->sets_valid ? (int64_t)ix->sets_off.size() - 1 : -1;
+}
+
+extern "C" int64_t dpf_sets_count(const dpf_index *ix, int64_t q0, int64_t q1)
+{
+    if (!ix || !ix->sets_valid) return -1;
+    const int64_t nq = (int64_t)ix->sets_off.size() - 1;
+    if (q0 < 0 || q1 < q0 || q1 > nq) return -1;
+    return ix->sets_off[(size_t)q1] - ix->sets_off[(size_t)q0];
+}
+
+extern "C" int dpf_sets_topk(dpf_index *ix, int32_t k, int32_t *ids, double *scores)
+{
+    if (!ix) return DPF_EINVAL;
+    if (!ix->sets_valid) return fail(ix, DPF_EINVAL, "dpf_sets_topk: no resident Sets (dpf_query_batch_resident first; any other query or fit call drops them)");
+    const int64_t nq = (int64_t)ix->sets_off.size() - 1;
+    if (k < 1 || k > 64 || (nq > 0 && (!ids || !scores))) return fail(ix, DPF_EINVAL, "dpf_sets_topk: bad arguments");
+    if (nq == 0) return DPF_OK;
+    HIPCHECK(ix, hipSetDevice(ix->cfg.device));
+    HIPCHECK(ix, ix->ws_hids.ensure((size_t)nq * k * 4));
+    HIPCHECK(ix, ix->ws_hscores.ensure((size_t)nq * k * 8));
+    RerankParams rp;
+    fill_rerank_params(ix, rp, ix->sets_qpad, k, ix->ws_misc.as<int64_t>(), nullptr, ix->ws_compact.as<int32_t>(), ix->ws_hids.as<int32_t>(),
+                       ix->ws_hscores.as<double>());
+    launch_rerank(ix->cfg.dtype, ix->cfg.metric, rp, nq, nullptr);
+    HIPCHECK(ix, hipGetLastError());
+    HIPCHECK(ix, hipMemcpy(ids, ix->ws_hids.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost));
+    HIPCHECK(ix, hipMemcpy(scores, ix->ws_hscores.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost));
+    return DPF_OK;
+}
+
+// The Sets in the handle's own pinned buffer (grown as needed, reused by the handle's next call).
+extern "C" int dpf_query_batch_view(dpf_index *ix, const int32_t *qids, const void *Q, int64_t nq, int32_t steps,
+                                    int64_t *cand_offsets, const int32_t **cand_ids)
+{
+    if (!ix) return DPF_EINVAL;
+    if (cand_ids) *cand_ids = nullptr;
+    bool empty;
+    int rc = sets_entry_checks(ix, Q, nq, steps, cand_offsets, "dpf_query_batch_view", &empty);
+    if (rc != DPF_OK) return rc;
+    if (!cand_ids) return fail(ix, DPF_EINVAL, "dpf_query_batch_view: bad arguments");
+    static const int32_t none = 0;
+    if (empty) { *cand_ids = &none; return DPF_OK; }
+    if ((rc = sets_to_device(ix, qids, Q, nq, steps, cand_offsets)) != DPF_OK) return rc;
     const int64_t total = cand_offsets[nq];
-    // The lists land in a pinned host buffer the handle keeps and grows (at c3 a batch's Sets are 2.9 GB of ids: into
-    // pinned memory they arrive at the link's rate, into fresh pageable memory at a tenth of it).  When pinned memory is
-    // not to be had the lists go to a malloc'd block the caller owns, as before.
+    // (at c3 a batch's Sets are 2.9 GB of ids: into pinned memory they arrive at the link's rate, into fresh pageable
+    // memory at a tenth of it)
     const size_t bytes = (size_t)std::max<int64_t>(total, 1) * 4;
-    int32_t *host = nullptr;
-    bool handle_owned = false;
     if (bytes > ix->h_sets_cap) {
-        std::lock_guard<std::mutex> lock(g_results_mutex);
-        if (ix->h_sets) {
-            for (size_t i = 0; i < g_handle_results.size(); i++)
-                if (g_handle_results[i] == ix->h_sets) { g_handle_results.erase(g_handle_results.begin() + i); break; }
-            (void)hipHostFree(ix->h_sets);
-            ix->h_sets = nullptr; ix->h_sets_cap = 0;
-        }
+        if (ix->h_sets) { (void)hipHostFree(ix->h_sets); ix->h_sets = nullptr; ix->h_sets_cap = 0; }
         void *q = nullptr;
         const size_t want = bytes + bytes / 4 + 4096;
-        if (hipHostMalloc(&q, want, hipHostMallocDefault) == hipSuccess) {
-            ix->h_sets = (int32_t *)q; ix->h_sets_cap = want;
-            g_handle_results.push_back(q);
-        } else {
+        if (hipHostMalloc(&q, want, hipHostMallocDefault) != hipSuccess) {
             (void)hipGetLastError();
+            return fail(ix, DPF_ENOMEM, "dpf_query_batch_view: no pinned host memory for " + std::to_string(bytes) + " bytes of lists (use dpf_query_batch_resident + dpf_sets_fetch in pieces)");
         }
+        ix->h_sets = (int32_t *)q; ix->h_sets_cap = want;
     }
-    if (ix->h_sets && bytes <= ix->h_sets_cap) { host = ix->h_sets; handle_owned = true; }
-    else host = (int32_t *)malloc(bytes);
+    if (total > 0) HIPCHECK(ix, hipMemcpy(ix->h_sets, ix->ws_compact.p, (size_t)total * 4, hipMemcpyDeviceToHost));
+    *cand_ids = ix->h_sets;
+    return DPF_OK;
+}
+
+// The Sets in a block the caller owns (dpf_free).
+extern "C" int dpf_query_batch(dpf_index *ix, const int32_t *qids, const void *Q, int64_t nq, int32_t steps,
+                               int64_t *cand_offsets, int32_t **cand_ids)
+{
+    if (!ix) return DPF_EINVAL;
+    if (cand_ids) *cand_ids = nullptr;
+    bool empty;
+    int rc = sets_entry_checks(ix, Q, nq, steps, cand_offsets, "dpf_query_batch", &empty);
+    if (rc != DPF_OK) return rc;
+    if (!cand_ids) return fail(ix, DPF_EINVAL, "dpf_query_batch: bad arguments");
+    if (empty) { *cand_ids = (int32_t *)malloc(4); return *cand_ids ? DPF_OK : fail(ix, DPF_ENOMEM, "dpf_query_batch: out of host memory"); }
+    if ((rc = sets_to_device(ix, qids, Q, nq, steps, cand_offsets)) != DPF_OK) return rc;
+    const int64_t total = cand_offsets[nq];
+    int32_t *host = (int32_t *)malloc((size_t)std::max<int64_t>(total, 1) * 4);
     if (!host) return fail(ix, DPF_ENOMEM, "dpf_query_batch: out of host memory");
-    if (total > 0) {
-        hipError_t e = ix->ws_compact.ensure((size_t)total * 4);
-        if (e == hipSuccess) {
-            launch_compact(ix->ws_arena.as<int32_t>(), ix->ws_off.as<int64_t>(), ix->ws_cnt.as<int32_t>(), ix->ws_misc.as<int64_t>(),
-                           ix->ws_compact.as<int32_t>(), nq, nullptr);
-            e = hipMemcpy(host, ix->ws_compact.p, (size_t)total * 4, hipMemcpyDeviceToHost);
+    // through the handle's pinned staging area, two pieces in flight: the copy engine fills one while the CPU empties the other
+    const size_t piece = (size_t)8 << 20, bytes = (size_t)total * 4, pieces = (bytes + piece - 1) / piece;
+    hipError_t e = total > 0 ? ix->h_stage.ensure(2 * piece) : hipSuccess;
+    for (size_t i = 0; e == hipSuccess && i < pieces + 1; i++) {
+        if (i < pieces) {                                 // (piece i - 2, which had this half, was emptied one round ago)
+            e = hipMemcpyAsync((char *)ix->h_stage.p + (i % 2) * piece, (const char *)ix->ws_compact.p + i * piece,
+                               std::min(piece, bytes - i * piece), hipMemcpyDeviceToHost, nullptr);
+            if (e == hipSuccess) e = hipEventRecord(ix->ev_stage[i % 2], nullptr);
         }
-        if (e != hipSuccess) { if (!handle_owned) free(host); ix->err = hipGetErrorString(e); return DPF_EHIP; }
+        if (e == hipSuccess && i >= 1) {
+            e = hipEventSynchronize(ix->ev_stage[(i - 1) % 2]);
+            if (e == hipSuccess) memcpy((char *)host + (i - 1) * piece, (const char *)ix->h_stage.p + ((i - 1) % 2) * piece, std::min(piece, bytes - (i - 1) * piece));
+        }
     }
+    if (e != hipSuccess) { (void)hipDeviceSynchronize(); free(host); ix->err = std::string("dpf_query_batch: ") + hipGetErrorString(e); return DPF_EHIP; }
     *cand_ids = host;
     return DPF_OK;
 }
 
 extern "C" void dpf_free(void *p)
 {
-    if (!p) return;
-    {
-        std::lock_guard<std::mutex> lock(g_results_mutex);
-        for (void *q : g_handle_results)
-            if (q == p) return;                           // a handle's own result buffer: reused by its next call
-    }
     free(p);
 }
 
@@ -1928,6 +2031,7 @@ extern "C" int dpf_rerank(dpf_index *ix, const void *Q, int64_t nq, const int64_
     if (nq == 0) return DPF_OK;
     const int64_t total = cand_offsets[nq];
     if (total < 0 || (total > 0 && !cand_ids)) return fail(ix, DPF_EINVAL, "dpf_rerank: bad candidate lists");
+    ix->sets_valid = false;
     HIPCHECK(ix, hipSetDevice(ix->cfg.device));
     const size_t qbytes = (size_t)nq * ix->cfg.dim * ix->elem;
     HIPCHECK(ix, ix->ws_hq.ensure(qbytes));

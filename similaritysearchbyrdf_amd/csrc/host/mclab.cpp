@@ -746,18 +746,17 @@ static void query_csr(State &S, const int32_t *qids, const double *Q, int64_t nq
         for (int64_t i = 0; i < nq; i++) std::cout << "need to fit the data first" << std::endl;
         return;
     }
-    int32_t *out = nullptr;
+    const int32_t *out = nullptr;                        // the handle's own buffer: copied at once
     int rc;
     if (S.store_f32) {
         std::vector<float> f((size_t)nq * S.dim);
         for (size_t i = 0; i < f.size(); i++) f[i] = (float)Q[i];
-        rc = dpf_query_batch(S.ix, qids, f.data(), nq, steps, offsets.data(), &out);
+        rc = dpf_query_batch_view(S.ix, qids, f.data(), nq, steps, offsets.data(), &out);
     } else {
-        rc = dpf_query_batch(S.ix, qids, Q, nq, steps, offsets.data(), &out);
+        rc = dpf_query_batch_view(S.ix, qids, Q, nq, steps, offsets.data(), &out);
     }
-    check(S, rc, "dpf_query_batch");
+    check(S, rc, "dpf_query_batch_view");
     ids.assign(out, out + offsets[(size_t)nq]);
-    dpf_free(out);
 }
 
 std::vector<std::set<int>> DensevectorRDFInit::NewMultiThreadQueryBatch(const std::vector<int> &queryArray,

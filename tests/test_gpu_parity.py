@@ -1185,24 +1185,53 @@ def test_first_radii_from_fp16_copies_or_exact_seeds(dim):
 
 
 @pytest.mark.gpu
-def test_set_lists_come_back_in_the_handles_own_buffer():
-    # dpf_query_batch hands its lists over in a pinned host buffer the handle keeps: the next call reuses it (grown when
-    # a batch needs more), dpf_free leaves it alone, and a copy taken before the next call stays what it was
+def test_three_ways_to_take_the_sets():
+    # NewMultiThreadQueryBatch's Sets (DensevectorRDFInit.scala:335-360): dpf_query_batch returns a block the caller owns;
+    # dpf_query_batch_view the handle's own pinned buffer, reused by the next call (a copy taken before stays what it
+    # was); dpf_query_batch_resident leaves them on the device for dpf_sets_fetch (any query range) and dpf_sets_topk
+    # (the rerank of DensevectorRDFInit.scala:477-505), until another query or fit call drops them
+    from similaritysearchbyrdf_amd._lib import DpfError, DPF_EINVAL
     params, X, Q, pick = make_problem(n=5000, nq=64, dim=48, bucket_overflow=40, table_num=2, permutation_num=2)
     orc, gpu = both(params, X)
     Q64 = Q.astype(np.float64)
+    want0 = orc.query_batch(pick, Q64, steps=0, threads=2, mode=1)
+    want1 = orc.query_batch(pick, Q64, steps=1, threads=2, mode=1)
     o1, v1 = gpu.query_batch(pick, Q, steps=0, copy=False)
     keep = v1.copy()
     at1 = v1.ctypes.data
-    o2, v2 = gpu.query_batch(pick, Q, steps=1, copy=False)          # smaller or equal lists fit the same buffer ...
+    o2, v2 = gpu.query_batch(pick, Q, steps=1, copy=False)          # the next call's lists take the buffer over (or a grown one)
     assert o2[-1] >= o1[-1]
-    o3, v3 = gpu.query_batch(pick[:8], Q[:8], steps=0, copy=False)
-    assert v3.ctypes.data == v2.ctypes.data
-    assert_same_sets((o3, v3.copy()), orc.query_batch(pick[:8], Q64[:8], steps=0, threads=2, mode=1))
-    assert_same_sets((o1, keep), orc.query_batch(pick, Q64, steps=0, threads=2, mode=1))
-    o4, v4 = gpu.query_batch(pick, Q, steps=3)                        # ... larger ones make it grow; the default is a copy
-    assert_same_sets((o4, v4), orc.query_batch(pick, Q64, steps=3, threads=2, mode=1))
-    assert at1 != 0
+    assert_same_sets((o2, np.asarray(v2).copy()), want1)
+    o3, v3 = gpu.query_batch(pick[:8], Q[:8], steps=0, copy=False)   # smaller lists fit the same buffer
+    assert v3.ctypes.data == v2.ctypes.data and at1 != 0
+    assert_same_sets((o3, np.asarray(v3).copy()), orc.query_batch(pick[:8], Q64[:8], steps=0, threads=2, mode=1))
+    assert_same_sets((o1, keep), want0)
+    o4, v4 = gpu.query_batch(pick, Q, steps=1)                       # the default: a block of the caller's own
+    assert_same_sets((o4, v4), want1)
+    assert v4.ctypes.data != v3.ctypes.data
+    # resident Sets: sizes first, lists on demand, top-k without ever moving the lists
+    off = gpu.query_batch_resident(pick, Q, steps=1)
+    assert np.array_equal(off, want1[0])
+    assert gpu.L_.dpf_sets_queries(gpu.h) == 64 and gpu.L_.dpf_sets_count(gpu.h, 3, 9) == off[9] - off[3]
+    for q0, q1 in ((0, 64), (5, 6), (17, 40), (63, 64), (10, 10)):
+        assert np.array_equal(gpu.sets_fetch(q0, q1), want1[1][off[q0]:off[q1]])
+    wi, ws = orc.topk(Q64, want1[0], want1[1], k=10, metric="dot")
+    ti, ts = gpu.sets_topk(10)
+    assert_topk_equal(ti, ts, wi, ws)
+    di, ds = gpu.query_topk(pick, Q, steps=1, k=10)                  # another query call: same answer, and the Sets are gone
+    assert np.array_equal(di, ti) and np.array_equal(ds, ts, equal_nan=True)
+    with pytest.raises(DpfError) as ei:
+        gpu.sets_fetch(0, 1)
+    assert ei.value.code == DPF_EINVAL and gpu.L_.dpf_sets_queries(gpu.h) == -1
+    # a batch large enough for several staging pieces (dpf_query_batch moves 8 MiB at a time)
+    params, X, Q, pick = make_problem(n=60000, nq=2000, dim=32, bucket_overflow=500, table_num=4, permutation_num=3, n_clusters=3)
+    big = DpfIndex(params, metric="l2")
+    big.fit(X)
+    ob, vb = big.query_batch(pick, Q, steps=3)
+    assert ob[-1] * 4 > 3 * (8 << 20), ob[-1]
+    ow, vw = big.query_batch(pick, Q, steps=3, copy=False)
+    assert np.array_equal(ob, ow) and np.array_equal(vb, np.asarray(vw))
+    big.close()
     gpu.close()
 
 

@@ -81,7 +81,8 @@ def test_shim_calls_only_declared_abi_functions():
     assert called and called <= declared, called - declared
     # the reference-facing entry points are all reachable from the JVM
     for must in ("dpf_create", "dpf_destroy", "dpf_set_hash_family", "dpf_set_partitioner", "dpf_set_sampling_index", "dpf_fit",
-                 "dpf_query_batch", "dpf_query_topk", "dpf_free", "dpf_last_error", "dpf_subindex_distribution"):
+                 "dpf_query_batch_view", "dpf_query_batch_resident", "dpf_sets_fetch", "dpf_sets_topk", "dpf_query_topk",
+                 "dpf_last_error", "dpf_subindex_distribution"):
         assert must in called, must
 
 

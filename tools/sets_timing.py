@@ -26,3 +26,12 @@ for rep in range(4):
 t0 = time.perf_counter()
 off, ids = ix.query_batch(pick, Q, steps=steps, copy=True)
 print("with a copy out of the handle's buffer: %.1f ms" % ((time.perf_counter() - t0) * 1e3), flush=True)
+t0 = time.perf_counter()
+off = ix.query_batch_resident(pick, Q, steps=steps)
+t1 = time.perf_counter()
+some = ix.sets_fetch(0, 100)
+t2 = time.perf_counter()
+ti, ts = ix.sets_topk(10)
+t3 = time.perf_counter()
+print("resident Sets: sizes in %.1f ms; the first 100 queries' lists (%.1f MB) in %.2f ms; top-10 of all %d Sets (gather rerank) in %.1f ms" % (
+    (t1 - t0) * 1e3, some.nbytes / 1e6, (t2 - t1) * 1e3, nq, (t3 - t2) * 1e3), flush=True)
