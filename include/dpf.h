@@ -371,10 +371,11 @@ enum {
                                         (default 0: an upper bound of the k-th best distance from the fp16 copies) */
     DPF_OPT_KEEP_FORWARDED = 11,     /* 1: every row the scan forwarded is scored exactly (default 0: rows forwarded under a
                                         threshold the query has tightened past since are dropped before the exact rerank) */
-    DPF_OPT_SIDE_STREAM = 12,        /* 0: every kernel of a batch is enqueued on the caller's stream (default 1: from the
-                                        handle's second batch on, the kernels that build the bucket lists run on a stream
-                                        of the handle's own beside those that find the first radii; both are ordered
-                                        behind the caller's stream and joined to it again before the scan) */
+    DPF_OPT_SIDE_STREAM = 12,        /* which kernels of a batch run on a stream of the handle's own beside the caller's (from the
+                                        handle's second batch on; both streams are ordered behind the caller's and joined to it
+                                        again before the scan): 0 = none, 2 = those that build the bucket lists (beside those that
+                                        find the first radii), 1 = also the conversions of the query rows (beside the hashing),
+                                        -1 (default) = 1 for handles that probe up to four tables, 2 otherwise */
     DPF_OPT_PROBE_LANES = 13,        /* the counting pass of the bucket-major path: 1 = a lane per (query, table, sub-index) that
                                         walks the hash's own path once and reads the sibling slots on it, 0 = a lane per probe (one
                                         bit flip of the hash) as the pass that materialises the Sets does, -1 (default) = the first

@@ -234,7 +234,7 @@ struct dpf_index {
     bool sizes_carried = false;                       // a bucket-major batch has sized leaf_queries[] / units[] already
     hipEvent_t ev[6]{};
     hipStream_t side_stream = nullptr;                // the list-building chain of a batch runs here, beside the first radii
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork0 = nullptr, ev_conv = nullptr;
     hipEvent_t ev_stage[2] = {nullptr, nullptr};      // the two halves of h_stage when results leave through it in pieces
     int last_path = 0;
     bool profiling = false;
@@ -253,7 +253,8 @@ struct dpf_index {
     bool build_pending = false;                       // rows were appended under opt_defer_build and the forest does not cover them yet
     int32_t opt_probe_lanes = -1;                     // -1: by the number of (table, sub-index) pairs a query probes
     int32_t last_q_leaf_cap = 0;                      // bucket-list capacity of the last bucket-major batch
-    bool opt_sync_sizes = false, opt_short_rerank = true, opt_exact_seeds = false, opt_keep_forwarded = false, opt_side_stream = true;
+    bool opt_sync_sizes = false, opt_short_rerank = true, opt_exact_seeds = false, opt_keep_forwarded = false;
+    int32_t opt_side_stream = -1;                     // 0: one stream; 1: conversions and lists on the side stream; 2: lists only; -1: by the forest
     int64_t opt_projection_min_rows = 4096;           // batches of at least this many vectors hash on the matrix cores (0: never)
 };
 
@@ -349,6 +350,8 @@ extern "C" int dpf_create(const dpf_config *cfg, dpf_index **out)
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ix->side_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ix->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ix->ev_join, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ix->ev_fork0, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ix->ev_conv, hipEventDisableTiming);
     for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipEventCreateWithFlags(&ix->ev_stage[i], hipEventDisableTiming);
     if (e != hipSuccess) {
         std::string m = std::string("dpf_create: ") + hipGetErrorString(e);
@@ -395,6 +398,8 @@ extern "C" void dpf_destroy(dpf_index *ix)
     for (int i = 0; i < 6; i++) if (ix->ev_scan[i]) (void)hipEventDestroy(ix->ev_scan[i]);
     if (ix->ev_fork) (void)hipEventDestroy(ix->ev_fork);
     if (ix->ev_join) (void)hipEventDestroy(ix->ev_join);
+    if (ix->ev_fork0) (void)hipEventDestroy(ix->ev_fork0);
+    if (ix->ev_conv) (void)hipEventDestroy(ix->ev_conv);
     for (int i = 0; i < 2; i++) if (ix->ev_stage[i]) (void)hipEventDestroy(ix->ev_stage[i]);
     if (ix->side_stream) (void)hipStreamDestroy(ix->side_stream);
     DevBuf *more[] = {&ix->ws_emit_ucnt, &ix->ws_emit_v, &ix->ws_leaf_units, &ix->ws_unit_off, &ix->ws_q_leaves, &ix->ws_q_leaf_cnt, &ix->d_leaf_tile0, &ix->ws_units, &ix->d_tiles, &ix->ws_lq_off, &ix->ws_lq_cursor, &ix->ws_leaf_queries,
@@ -1330,13 +1335,62 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     HIPCHECK(ix, ix->ws_flag.ensure(lq_cnt_bytes + flag_bytes));
     HIPCHECK(ix, ix->ws_tau.ensure((size_t)nq * 4));
 
+    // what the scan reads of the queries (fp16 rows, norms, rounding distances, tails; int8 rows where the index has them)
+    HIPCHECK(ix, ix->ws_q16.ensure((size_t)nq * ix->ks16 * 32 * 2));
+    HIPCHECK(ix, ix->ws_q16n.ensure((size_t)nq * 4));
+    HIPCHECK(ix, ix->ws_q16e.ensure((size_t)nq * 4));
+    HIPCHECK(ix, ix->ws_qc.ensure((size_t)nq * 16));
+    const bool tails = ix->filter_dim < ix->cfg.dim;
+    if (tails) HIPCHECK(ix, ix->ws_q16t.ensure((size_t)nq * 16));
+    const bool i8 = ix->i8_ok && ix->d_slot_nj8.p != nullptr;
+    if (i8) {
+        HIPCHECK(ix, ix->ws_q8.ensure((size_t)nq * ix->ks8 * 64));
+        HIPCHECK(ix, ix->ws_qc8.ensure((size_t)nq * 16));
+    }
+    HIPCHECK(ix, ix->ws_emit_v.ensure((size_t)nq * EMIT_CAP * 4));
+    int32_t *const i8_gate = (int32_t *)flag_block_of(ix) + 8;    // raised when a query does not fit the int8 window
+    // l2: the first radii come from the fp16 copies (k_seed_radius, behind the query conversion: an upper bound is
+    // all the scan needs, at half the bytes per seed row); dot, or on request: exact scores of the fp32 rows
+    const bool seeds_fp16 = SEED_CAP > 0 && ix->cfg.metric == DPF_METRIC_L2 && !ix->opt_exact_seeds;
+    // With carried sizes - nothing for the host to read in between - two chains of a batch run on the handle's side
+    // stream beside the caller's: the conversions of the query rows (they need only the rows: beside the hashing) and,
+    // behind the first probe pass, the lists (offset scans, k_fill_lists, work units: beside the first radii).
+    const bool carried = ix->sizes_carried && !ix->opt_sync_sizes;
+    const bool fork = carried && ix->opt_side_stream && !ix->profiling && ix->side_stream != nullptr;
+    // (an early return between a fork and its join - a failed call, a workspace that cannot grow - must not leave
+    // the side stream's kernels writing the handle's buffers behind the caller's back: the guard waits them out)
+    struct SideGuard {
+        hipStream_t side = nullptr;
+        ~SideGuard() { if (side) { (void)hipStreamSynchronize(side); (void)hipGetLastError(); } }
+    } side_guard;
+    auto convert_queries = [&](hipStream_t cs, const TauParams *tp) {
+        launch_rows_to_f16((const float *)qpad, ix->dpad, std::min(ix->cfg.dim, ix->filter_dim), nq, ix->ws_q16.as<uint16_t>(), ix->ks16 * 32,
+                           ix->ws_q16n.as<float>(), ix->ws_q16e.as<float>(), cs, tp, ix->cfg.dim,
+                           tails ? (uint4 *)ix->ws_q16t.p : nullptr, ix->centred ? ix->d_mu.as<float>() : nullptr);
+        if (i8)
+            launch_rows_to_i8((const float *)qpad, ix->dpad, ix->cfg.dim, nq, ix->i8_offset, ix->ws_q8.as<int8_t>(), ix->ks8 * 64, nullptr,
+                              (float4 *)ix->ws_qc8.p, d_qids, i8_gate, cs);
+    };
+
     if (ix->profiling) HIPCHECK(ix, hipEventRecord(ix->ev[0], stream));
+    // (the memset comes first: the int8 conversion raises a word inside what it clears)
+    HIPCHECK(ix, hipMemsetAsync(ix->ws_flag.p, 0, lq_cnt_bytes + flag_bytes, stream));
+    // (the conversions beside the hashing: measured -2.5 % per batch on a single tree, whose hashing is short, +0.8 % on 30
+    // trees, where they get in the hash kernel's way: by default only for handles that probe up to four tables)
+    const int probed_tables = (ix->cfg.table_end > 0 ? ix->cfg.table_end : L) - ix->cfg.table_begin;
+    const bool conv_early = fork && seeds_fp16 && (ix->opt_side_stream == 1 || (ix->opt_side_stream < 0 && probed_tables <= 4));
+    if (conv_early) {
+        HIPCHECK(ix, hipEventRecord(ix->ev_fork0, stream));
+        HIPCHECK(ix, hipStreamWaitEvent(ix->side_stream, ix->ev_fork0, 0));
+        side_guard.side = ix->side_stream;
+        convert_queries(ix->side_stream, nullptr);
+        HIPCHECK(ix, hipEventRecord(ix->ev_conv, ix->side_stream));
+    }
     {
         const int hrc = hash_rows(ix, qpad, qstride, nq, ix->ws_hashes.as<int32_t>(), ix->ws_parts.as<int32_t>(), stream);
         if (hrc != DPF_OK) return hrc;
     }
     if (ix->profiling) HIPCHECK(ix, hipEventRecord(ix->ev[1], stream));
-    HIPCHECK(ix, hipMemsetAsync(ix->ws_flag.p, 0, lq_cnt_bytes + flag_bytes, stream));
     ProbeParams pp;
     fill_probe_params(ix, pp, d_qids, steps, handle_ws(ix));
     pp.lq_cnt = lq_cnt_of(ix);
@@ -1371,23 +1425,11 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     // batch of a handle reads them back here; later batches do not wait: the kernels behind this point take the
     // totals from device memory, the buffers keep the headroom earlier batches left them, and a batch that
     // outgrows them (or truncated a bucket list) raises a flag, writes nothing and is run again the slow way.
-    const bool carried = ix->sizes_carried && !ix->opt_sync_sizes;
     const int64_t cap_pairs = std::min<int64_t>((int64_t)(ix->ws_leaf_queries.cap / 4), 0xfffffffell);
     const int64_t cap_units = std::min<int64_t>((int64_t)(ix->ws_units.cap / 16), 0xfffffffell);
     int32_t *const flags = (int32_t *)flag_block_of(ix);
     int64_t *const d_totals = (int64_t *)(flag_block_of(ix) + 16);
-    // Behind the first probe pass a batch has two chains that meet again at the scan: the lists (offset scans,
-    // k_fill_lists, work units) and the first radii (seed sample, query conversions, k_seed_radius).  Neither reads what
-    // the other writes.  With carried sizes - nothing for the host to read in between - the list chain runs on the
-    // handle's side stream, beside the radii.
-    const bool fork = carried && ix->opt_side_stream && !ix->profiling && ix->side_stream != nullptr;
     hipStream_t ls = stream;
-    // (an early return between the fork and the join - a failed call, a workspace that cannot grow - must not leave
-    // the side stream's kernels writing the handle's buffers behind the caller's back: the guard waits them out)
-    struct SideGuard {
-        hipStream_t side = nullptr;
-        ~SideGuard() { if (side) { (void)hipStreamSynchronize(side); (void)hipGetLastError(); } }
-    } side_guard;
     if (fork) {
         HIPCHECK(ix, hipEventRecord(ix->ev_fork, stream));
         HIPCHECK(ix, hipStreamWaitEvent(ix->side_stream, ix->ev_fork, 0));
@@ -1441,47 +1483,29 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
         launch_unique_lists(ix->ws_seed_cand.as<int32_t>(), ix->ws_seed_cnt.as<int32_t>(), SEED_CAP, SEED_CAP, ix->ws_emit_ucnt.as<int32_t>(), nq, stream);
         rp.cnt = ix->ws_emit_ucnt.as<int32_t>();
     }
-    // l2: the first radii come from the fp16 copies (k_seed_radius, behind the query conversion below: an upper bound is
-    // all the scan needs, at half the bytes per seed row); dot, or on request: exact scores of the fp32 rows
-    const bool seeds_fp16 = SEED_CAP > 0 && ix->cfg.metric == DPF_METRIC_L2 && !ix->opt_exact_seeds;
     if (SEED_CAP > 0 && !seeds_fp16) {
         if (short_lists && rerank_short_applies(rp)) launch_rerank_short(ix->cfg.dtype, ix->cfg.metric, rp, nq, stream);
         else launch_rerank(ix->cfg.dtype, ix->cfg.metric, rp, nq, stream);
     }
 
-    // fp16 copies of the queries, first thresholds, the work list, the scan
-    HIPCHECK(ix, ix->ws_q16.ensure((size_t)nq * ix->ks16 * 32 * 2));
-    HIPCHECK(ix, ix->ws_q16n.ensure((size_t)nq * 4));
-    HIPCHECK(ix, ix->ws_q16e.ensure((size_t)nq * 4));
-    HIPCHECK(ix, ix->ws_qc.ensure((size_t)nq * 16));
+    // fp16 copies of the queries (unless they were made beside the hashing), first thresholds
     {   // the conversion's last lane of every query row also writes the query's first threshold and scan record
         TauParams tp;
         tp.metric = ix->cfg.metric;
         if (SEED_CAP > 0 && !seeds_fp16) { tp.seed_scores = ix->ws_seed_scores.as<double>(); tp.seed_ids = ix->ws_seed_ids.as<int32_t>(); }
         tp.k = k; tp.qids = d_qids; tp.tau = ix->ws_tau.as<int32_t>(); tp.qc = (float4 *)ix->ws_qc.p;
-        const bool tails = ix->filter_dim < ix->cfg.dim;
-        if (tails) HIPCHECK(ix, ix->ws_q16t.ensure((size_t)nq * 16));
-        launch_rows_to_f16((const float *)qpad, ix->dpad, std::min(ix->cfg.dim, ix->filter_dim), nq, ix->ws_q16.as<uint16_t>(), ix->ks16 * 32,
-                           ix->ws_q16n.as<float>(), ix->ws_q16e.as<float>(), stream, seeds_fp16 ? nullptr : &tp, ix->cfg.dim,
-                           tails ? (uint4 *)ix->ws_q16t.p : nullptr, ix->centred ? ix->d_mu.as<float>() : nullptr);
+        if (conv_early) HIPCHECK(ix, hipStreamWaitEvent(stream, ix->ev_conv, 0));
+        else convert_queries(stream, seeds_fp16 ? nullptr : &tp);
         if (seeds_fp16)
             launch_seed_radius(rp.cand, rp.cnt, SEED_CAP, ix->ws_q16.as<uint16_t>(), ix->d_base16.as<uint16_t>(), ix->ks16,
                                ix->ws_q16n.as<float>(), ix->ws_q16e.as<float>(), ix->d_base16e.as<float>(),
                                tails ? (const uint4 *)ix->ws_q16t.p : nullptr, tails ? (const uint4 *)ix->d_base16t.p : nullptr,
                                ix->row_begin, ix->row_begin + ix->base_rows, tp, nq, stream);
     }
-    // int8 rows of the queries where the index has an int8 copy; flags[8] is raised when a query does not fit its window
-    int32_t *const i8_gate = flags + 8;
-    const bool i8 = ix->i8_ok && ix->d_slot_nj8.p != nullptr;
-    if (i8) {
-        HIPCHECK(ix, ix->ws_q8.ensure((size_t)nq * ix->ks8 * 64));
-        HIPCHECK(ix, ix->ws_qc8.ensure((size_t)nq * 16));
-        launch_rows_to_i8((const float *)qpad, ix->dpad, ix->cfg.dim, nq, ix->i8_offset, ix->ws_q8.as<int8_t>(), ix->ks8 * 64, nullptr,
-                          (float4 *)ix->ws_qc8.p, d_qids, i8_gate, stream);
-    }
-    HIPCHECK(ix, ix->ws_emit_v.ensure((size_t)nq * EMIT_CAP * 4));
     if (fork) {                                                             // the scan needs both chains
         HIPCHECK(ix, hipStreamWaitEvent(stream, ix->ev_join, 0));
+        side_guard.side = nullptr;
+    } else if (conv_early) {
         side_guard.side = nullptr;
     }
     LeafScanParams lp;
@@ -2120,7 +2144,8 @@ extern "C" int dpf_set_option(dpf_index *ix, int32_t option, int64_t value)
         ix->opt_keep_forwarded = value != 0;
         return DPF_OK;
     case DPF_OPT_SIDE_STREAM:
-        ix->opt_side_stream = value != 0;
+        if (value < -1 || value > 2) return fail(ix, DPF_EINVAL, "dpf_set_option: side stream must be -1 (by the forest), 0, 1 or 2");
+        ix->opt_side_stream = (int32_t)value;
         return DPF_OK;
     case DPF_OPT_EXACT_SEEDS:
         ix->opt_exact_seeds = value != 0;
