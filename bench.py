@@ -658,6 +658,7 @@ def main():
                        "unique_candidates_per_query_on_rank0": (st["last_unique_candidates"] / nq) if st["last_path"] == 0 else None,
                        "bucket_incidences_per_query_on_rank0": st["last_pairs"] / nq,
                        "forwarded_to_exact_rerank_per_query_on_rank0": st["last_forwarded"] / nq,
+                       "longest_forward_list_on_rank0": st["last_longest_list"],
                        "misflag_events": st["misflag_events"], "short_hash_events": st["short_hash_events"]},
             "roofline": roofline,
         }

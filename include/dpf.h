@@ -155,6 +155,7 @@ typedef struct dpf_stats {
     int64_t base8_bytes;             /* HBM bytes of the int8 copy of the resident rows (0: the rows do not allow one)   */
     int64_t last_scan_int8;          /* 1: the last bucket-major batch was scanned in int8, 0: in fp16                    */
     int64_t bucket_order_bytes;      /* HBM bytes of the bucket-order copy of the fp16 rows (0: the scan gathers its rows by id) */
+    int64_t last_longest_list;       /* last bucket-major batch: entries of the longest forward list (before duplicates are dropped) */
     int64_t debug_bound_violations;  /* since dpf_create: indices outside their arrays met by the scan's loaders; only a build of
                                         the library with -DDPF_DEBUG_BOUNDS looks (and clamps them); always 0 otherwise        */
 } dpf_stats;
@@ -337,6 +338,11 @@ int dpf_snapshot_copy(dpf_index *ix, uint32_t *roots, uint32_t *dnodes, uint32_t
  * 0xffffffff padded).  NULL skips an array. */
 int dpf_last_incidences(dpf_index *ix, uint32_t *bucket_counts, uint64_t *ids_visited, int32_t *buckets_reached,
                         uint32_t *bucket_lists, int32_t list_cap);
+
+/* Per query of the last bucket-major top-k batch: rows the scan forwarded to the exact rerank (`forwarded`, before
+ * duplicates are dropped) and rows the exact rerank scored in the end (`kept`: distinct, and not passed by the query's
+ * final threshold).  For inspection; NULL skips an array. */
+int dpf_last_forward_counts(dpf_index *ix, int32_t *forwarded, int32_t *kept);
 
 /* Device time of the dominant kernel of the last *_topk* call, measured with HIP
  * events on the stream the kernel ran on, and the bytes that launch has to move by

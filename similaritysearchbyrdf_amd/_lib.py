@@ -40,7 +40,7 @@ class DpfStats(C.Structure):
         (n, C.c_int64) for n in ("last_overflowed", "last_sizes_carried", "total_topk_batches", "total_sized_on_host",
                                  "total_carried", "total_rerun", "total_overflowed", "total_gather_batches",
                                  "base16_bytes", "tile_rows", "num_tiles", "resident_ids", "hash_undecided_rows",
-                                 "base8_bytes", "last_scan_int8", "bucket_order_bytes", "debug_bound_violations")]
+                                 "base8_bytes", "last_scan_int8", "bucket_order_bytes", "last_longest_list", "debug_bound_violations")]
 
 
 EXPORTS = (
@@ -51,7 +51,7 @@ EXPORTS = (
     "dpf_save", "dpf_load", "dpf_get_config", "dpf_snapshot_sizes", "dpf_snapshot_copy", "dpf_set_option", "dpf_query_topk_device_static",
     "dpf_load_shard", "dpf_set_probe_mode", "dpf_host_alloc", "dpf_host_free", "dpf_last_incidences",
     "dpf_query_batch_view", "dpf_query_batch_resident", "dpf_sets_fetch", "dpf_sets_topk",
-    "dpf_sets_queries", "dpf_sets_count",
+    "dpf_sets_queries", "dpf_sets_count", "dpf_last_forward_counts",
 )
 
 # dpf_set_option keys (include/dpf.h)
@@ -148,6 +148,8 @@ def lib():
     L.dpf_get_config.argtypes = [vp, C.POINTER(DpfConfig)]
     L.dpf_last_incidences.restype = C.c_int
     L.dpf_last_incidences.argtypes = [vp, vp, vp, vp, vp, C.c_int32]
+    L.dpf_last_forward_counts.restype = C.c_int
+    L.dpf_last_forward_counts.argtypes = [vp, vp, vp]
     L.dpf_host_alloc.restype = C.c_int
     L.dpf_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
     L.dpf_host_free.restype = None
@@ -463,6 +465,13 @@ class DpfIndex:
         self._check(self.L_.dpf_last_incidences(self.h, bc.ctypes.data, raw.ctypes.data, br.ctypes.data,
                                                 bl.ctypes.data if list_cap > 0 else None, list_cap))
         return bc, raw, br, bl
+
+    def last_forward_counts(self, nq):
+        """(forwarded [nq], kept [nq]) of the last bucket-major top-k batch."""
+        f = np.zeros(nq, dtype=np.int32)
+        kpt = np.zeros(nq, dtype=np.int32)
+        self._check(self.L_.dpf_last_forward_counts(self.h, f.ctypes.data, kpt.ctypes.data))
+        return f, kpt
 
     def last_rerank_profile(self):
         ms = C.c_double()

@@ -1594,6 +1594,7 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     const int64_t n_ovf = (int32_t)(ix->pinned[4] & 0xffffffff);
     const int32_t longest = (int32_t)(ix->pinned[5] & 0xffffffff);
     ix->st.last_overflowed = n_ovf;
+    ix->st.last_longest_list = longest;
     if (n_ovf > 0 && ix->opt_emit_cap <= 0 && ix->emit_cap < 65536) ix->emit_cap *= 2;   // from the next batch on
     if (n_ovf * 8 > nq) return DPF_OK;
 
@@ -2276,6 +2277,17 @@ extern "C" int dpf_last_incidences(dpf_index *ix, uint32_t *bucket_counts, uint6
             for (int32_t i = 0; i < list_cap; i++) bucket_lists[(size_t)q * list_cap + i] = i < n ? row[(size_t)i].x : 0xffffffffu;
         }
     }
+    return DPF_OK;
+}
+
+extern "C" int dpf_last_forward_counts(dpf_index *ix, int32_t *forwarded, int32_t *kept)
+{
+    if (!ix) return DPF_EINVAL;
+    if (!ix->last_valid || ix->last_path != 1 || ix->last_nq <= 0) return fail(ix, DPF_EINVAL, "dpf_last_forward_counts: the last batch did not take the bucket-major path");
+    HIPCHECK(ix, hipSetDevice(ix->cfg.device));
+    HIPCHECK(ix, hipDeviceSynchronize());
+    if (forwarded) HIPCHECK(ix, hipMemcpy(forwarded, emit_cnt_of(ix), (size_t)ix->last_nq * 4, hipMemcpyDeviceToHost));
+    if (kept && ix->ws_emit_ucnt.p) HIPCHECK(ix, hipMemcpy(kept, ix->ws_emit_ucnt.p, (size_t)ix->last_nq * 4, hipMemcpyDeviceToHost));
     return DPF_OK;
 }
 

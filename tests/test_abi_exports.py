@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header():
     from similaritysearchbyrdf_amd import _lib
     assert C.sizeof(_lib.DpfConfig) == 20 * 4 + 2 * 8
-    assert C.sizeof(_lib.DpfStats) == 8 * 8 + 5 * 8 + 6 * 8 + 3 * 8 + 17 * 8
+    assert C.sizeof(_lib.DpfStats) == 8 * 8 + 5 * 8 + 6 * 8 + 3 * 8 + 18 * 8
 
 
 def test_create_without_gpu_fails_loudly():
