@@ -390,6 +390,12 @@ enum {
                                         scan's copies unbuilt (queries are refused with DPF_ENOTFIT meanwhile); the first dpf_fit
                                         after the option is cleared (n = 0 will do) builds them once over everything appended.
                                         For a base streamed in chunk by chunk: one forest build instead of one per chunk */
+    DPF_OPT_LIST_BINS = 16,          /* 0: the bucket lists of a batch are always built from a global incidence histogram (returning
+                                        atomics), its scan and scattered stores.  Default 1: from the handle's second batch on the
+                                        counting pass writes (bucket, query) pairs into per-bin regions - a bin is a range of buckets;
+                                        the bins are cut from the first batch's counts to hold about equally many pairs - and one
+                                        workgroup per bin builds counts, offsets and lists in LDS.  2: as 1, the list entries stored
+                                        one by one instead of staged in LDS (measurement) */
     DPF_OPT_EXPECTED_ROWS = 15       /* ids the caller is going to fit in all (0 = unknown): the next dpf_fit sizes the row and hash
                                         buffers for them at once instead of regrowing them chunk by chunk */
 };

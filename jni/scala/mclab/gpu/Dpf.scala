@@ -37,6 +37,7 @@ object Dpf {
   val OptProbeLanes = 13
   val OptDeferBuild = 14
   val OptExpectedRows = 15
+  val OptListBins = 16
   // DPF_FLAG_* of dpf_config.flags
   val FlagHashOnly = 1
   val FlagGatherOnly = 2

@@ -57,7 +57,7 @@ EXPORTS = (
 # dpf_set_option keys (include/dpf.h)
 OPTION = {"emit_cap": 1, "bucket_list_cap": 2, "sync_sizes": 3, "first_pass_permille": 4, "seed_sample": 5,
           "short_rerank": 6, "projection_min_rows": 7, "scan_passes": 8, "early_pass_permille": 9, "exact_seeds": 10, "keep_forwarded": 11, "side_stream": 12, "probe_lanes": 13,
-          "defer_build": 14, "expected_rows": 15}
+          "defer_build": 14, "expected_rows": 15, "list_bins": 16}
 
 _lib = None
 

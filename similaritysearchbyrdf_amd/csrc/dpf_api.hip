@@ -51,6 +51,7 @@ constexpr size_t SCRATCH_BYTES = SCRATCH_OFF_ARENA + SCRATCH_ARENA_IDS * 4;     
 static_assert(SCRATCH_OFF_ARENA % 256 == 0 && SCRATCH_OFF_CNT % 256 == 0 && SCRATCH_OFF_OFF % 256 == 0, "256-byte aligned slices");
 
 constexpr int SCRATCH_MAX_DEVICES = 64;
+constexpr int MAX_BINS = BIN_MAX;                                     // bins of buckets of the binned list building
 // Per GPU: where its copy of the array lives, an event recorded behind the last kernel of the last call that used it
 // (the next call's stream waits for it, so that calls on different streams or from different handles never overlap
 // on the device), and a lock held for the host part of a call (a second thread calling meanwhile is refused with
@@ -251,6 +252,15 @@ struct dpf_index {
     bool opt_defer_build = false;                     // dpf_fit appends rows and hashes only; the forest is built by the first dpf_fit after it is cleared
     int64_t opt_expected_rows = 0;                    // ids the caller is going to fit in all: buffers are sized for them at once
     bool build_pending = false;                       // rows were appended under opt_defer_build and the forest does not cover them yet
+    // Binned list building (batches with carried sizes): the buckets are grouped into nbins bins, ranges of whole granules
+    // (1 << gran_shift buckets, ngran of them; d_bin_map: granule -> bin, d_bin_lo: first bucket of each bin) that held about
+    // equally many incidences in the last batch sized on the host; the counting pass writes (bucket, query) pairs into
+    // per-bin regions of ws_pairs (capacities d_bin_cap, offsets d_bin_off: twice what that batch needed), one workgroup
+    // per bin then builds the lists in LDS
+    int32_t gran_shift = 0, ngran = 0, nbins = 0;
+    bool bins_seeded = false;
+    DevBuf d_bin_cap, d_bin_off, d_bin_map, d_bin_lo, d_gran_cnt, ws_pairs, ws_bin_units, ws_bin_unit_base;
+    int32_t opt_list_bins = 1;
     int32_t opt_probe_lanes = -1;                     // -1: by the number of (table, sub-index) pairs a query probes
     int32_t last_q_leaf_cap = 0;                      // bucket-list capacity of the last bucket-major batch
     bool opt_sync_sizes = false, opt_short_rerank = true, opt_exact_seeds = false, opt_keep_forwarded = false;
@@ -342,8 +352,8 @@ extern "C" int dpf_create(const dpf_config *cfg, dpf_index **out)
     if (e == hipSuccess) ix->scratch_ptr = (unsigned char *)scratch_of(cfg->device, &e);
     if (e == hipSuccess) e = hipMalloc((void **)&ix->d_short_hash, sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(ix->d_short_hash, 0, sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMalloc((void **)&ix->d_proj_counters, 32);
-    if (e == hipSuccess) e = hipMemset(ix->d_proj_counters, 0, 32);
+    if (e == hipSuccess) e = hipMalloc((void **)&ix->d_proj_counters, 48);
+    if (e == hipSuccess) e = hipMemset(ix->d_proj_counters, 0, 48);
     if (e == hipSuccess) e = hipHostMalloc((void **)&ix->pinned, 12 * sizeof(int64_t), hipHostMallocDefault);
     for (int i = 0; i < 6 && e == hipSuccess; i++) e = hipEventCreate(&ix->ev[i]);
     for (int i = 0; i < 6 && e == hipSuccess; i++) e = hipEventCreate(&ix->ev_scan[i]);
@@ -404,7 +414,7 @@ extern "C" void dpf_destroy(dpf_index *ix)
     if (ix->side_stream) (void)hipStreamDestroy(ix->side_stream);
     DevBuf *more[] = {&ix->ws_emit_ucnt, &ix->ws_emit_v, &ix->ws_leaf_units, &ix->ws_unit_off, &ix->ws_q_leaves, &ix->ws_q_leaf_cnt, &ix->d_leaf_tile0, &ix->ws_units, &ix->d_tiles, &ix->ws_lq_off, &ix->ws_lq_cursor, &ix->ws_leaf_queries,
                       &ix->ws_seed_cand, &ix->ws_seed_cnt, &ix->ws_seed_ids, &ix->ws_seed_scores, &ix->ws_emit, &ix->ws_emit_cnt,
-                      &ix->d_base16, &ix->d_slot16, &ix->ws_q16, &ix->d_base16n, &ix->ws_q16n, &ix->d_base16e, &ix->ws_q16e, &ix->ws_flag, &ix->ws_tau, &ix->ws_qc, &ix->d_slot_norm, &ix->d_base16t, &ix->d_slot_tail, &ix->ws_q16t, &ix->ws_ovf, &ix->d_base8, &ix->d_norm8, &ix->d_slot_nj8, &ix->d_i8_probe, &ix->ws_q8, &ix->ws_qc8, &ix->d_mu, &ix->d_bounds, &ix->sub_q, &ix->sub_qids, &ix->sub_ids,
+                      &ix->d_base16, &ix->d_slot16, &ix->d_bin_cap, &ix->d_bin_off, &ix->d_bin_map, &ix->d_bin_lo, &ix->d_gran_cnt, &ix->ws_pairs, &ix->ws_bin_units, &ix->ws_bin_unit_base, &ix->ws_q16, &ix->d_base16n, &ix->ws_q16n, &ix->d_base16e, &ix->ws_q16e, &ix->ws_flag, &ix->ws_tau, &ix->ws_qc, &ix->d_slot_norm, &ix->d_base16t, &ix->d_slot_tail, &ix->ws_q16t, &ix->ws_ovf, &ix->d_base8, &ix->d_norm8, &ix->d_slot_nj8, &ix->d_i8_probe, &ix->ws_q8, &ix->ws_qc8, &ix->d_mu, &ix->d_bounds, &ix->sub_q, &ix->sub_qids, &ix->sub_ids,
                       &ix->sub_scores, &ix->sub_ws[0], &ix->sub_ws[1], &ix->sub_ws[2], &ix->sub_ws[3], &ix->sub_ws[4], &ix->sub_ws[5]};
     for (DevBuf *b : more) b->release();
     delete ix;
@@ -600,6 +610,20 @@ static int make_slot_order_rows(dpf_index *ix, int64_t num_ids)
     return DPF_OK;
 }
 
+// granules of buckets for the binned list building: the smallest power of two (16 or more) that gives at most
+// BIN_MAX_GRANULES of them; the bins themselves are cut from a batch's counts (k_bin_seed)
+static void setup_bins(dpf_index *ix)
+{
+    ix->bins_seeded = false;
+    ix->gran_shift = 0; ix->ngran = 0; ix->nbins = 0;
+    const int64_t nl = ix->num_leaves;
+    if (nl <= 0 || nl >= ((int64_t)1 << BIN_LEAF_BITS)) return;   // more buckets than that: the lists are built the other way
+    int shift = 4;
+    while (((nl + ((int64_t)1 << shift) - 1) >> shift) > BIN_MAX_GRANULES) shift++;
+    ix->gran_shift = shift;
+    ix->ngran = (int32_t)((nl + ((int64_t)1 << shift) - 1) >> shift);
+}
+
 static int upload_snapshot(dpf_index *ix, ForestSnapshot &s)
 {
     int rc;
@@ -636,6 +660,7 @@ static int upload_snapshot(dpf_index *ix, ForestSnapshot &s)
     ix->auto_seed_cap = seed_sample_for(ix);
     ix->ntiles = ix->nutiles;
     ix->num_leaves = (int64_t)s.leaf_off.size() - 1;
+    setup_bins(ix);
     if ((rc = upload(ix, ix->d_roots, s.roots)) != DPF_OK) return rc;
     if ((rc = upload(ix, ix->d_dnodes, s.dnodes)) != DPF_OK) return rc;
     if ((rc = upload(ix, ix->d_leaf_off, s.leaf_off)) != DPF_OK) return rc;
@@ -714,6 +739,7 @@ static int device_snapshot(dpf_index *ix, int64_t total)
     ix->d_tiles.adopt(tiles, std::max<size_t>((size_t)ntiles * 16, 16));
     ix->nutiles = ix->ntiles = ntiles;
     ix->num_leaves = f.num_leaves;
+    setup_bins(ix);
     std::vector<uint32_t> off((size_t)f.num_leaves + 1, 0u);
     HIPCHECK(ix, hipMemcpy(off.data(), ix->d_leaf_off.p, off.size() * 4, hipMemcpyDeviceToHost));
     ix->h_leaf_len.resize((size_t)f.num_leaves);
@@ -1293,7 +1319,9 @@ static void fill_rerank_params(dpf_index *ix, RerankParams &rp, const void *d_Qp
 // launches (each counter on a 128-byte line of its own)
 static const int TICKET_COUNTERS = 16;
 static const int MAX_SCAN_PASSES = 3;
-static const size_t FLAG_BYTES = 128 + MAX_SCAN_PASSES * (size_t)TICKET_COUNTERS * 128;
+// behind the ticket counters: the bins' pair counters of the binned list building (MAX_BINS words)
+static const size_t BIN_CURSOR_OFF = 128 + MAX_SCAN_PASSES * (size_t)TICKET_COUNTERS * 128;
+static const size_t FLAG_BYTES = BIN_CURSOR_OFF + (size_t)MAX_BINS * 4;
 // the per-query forward counts sit behind them, so that one memset clears everything a batch starts from
 // Everything a batch starts from at zero sits in ONE buffer, cleared by one memset: the per-bucket incidence
 // histogram lq_cnt[num_leaves + 1] first (its size only changes with a fit), the flag block behind it.
@@ -1409,6 +1437,7 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
         pp.q_leaf_cnt = ix->ws_q_leaf_cnt.as<int32_t>();
         pp.q_leaf_overflow = (int32_t *)flag_block_of(ix) + 1;
     }
+    bool use_bins = false;
     {
         // The counting pass: a lane per (query, table, sub-index) where a query has few of those (a single tree: a wave
         // per table leaves k_probe<0> mostly idle; 18 instead of 25 us on 10k queries), a lane per probe otherwise (30
@@ -1418,7 +1447,19 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
         for (int s2 = 0; s2 < ix->geo.num_parts; s2++) nsub += __builtin_popcount((unsigned)s2) <= steps;
         const int lanes_per_query = (pp.t_end - pp.t_begin) * nsub;
         const bool lanes = ix->opt_probe_lanes >= 0 ? ix->opt_probe_lanes != 0 : lanes_per_query <= 16;
-        if (!(lanes && launch_probe_lanes(pp, nq, stream))) launch_probe(0, pp, nq, stream);
+        // With carried sizes and bins seeded by an earlier batch: the binned form (no incidence atomics; the lists are
+        // built from the pairs bin by bin, below).
+        if (carried && ix->bins_seeded && ix->opt_list_bins && ix->nbins > 0) {
+            ProbeParams bp = pp;
+            bp.bin_cursor = (uint32_t *)(flag_block_of(ix) + BIN_CURSOR_OFF);
+            bp.bin_cap = ix->d_bin_cap.as<uint32_t>(); bp.bin_off = ix->d_bin_off.as<uint32_t>();
+            bp.bin_map = ix->d_bin_map.as<uint16_t>();
+            bp.pairs = ix->ws_pairs.as<uint2>();
+            bp.gran_shift = ix->gran_shift; bp.nbins = ix->nbins;
+            bp.bin_overflow = (int32_t *)flag_block_of(ix) + 3;
+            use_bins = launch_probe_lanes(bp, nq, stream);
+        }
+        if (!use_bins && !(lanes && launch_probe_lanes(pp, nq, stream))) launch_probe(0, pp, nq, stream);
     }
     HIPCHECK(ix, ix->ws_unit_off.ensure((size_t)(nl + 2) * 8));
     // The two totals of the batch (bucket incidences, work units) size leaf_queries[] and units[].  The first
@@ -1436,9 +1477,26 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
         ls = ix->side_stream;
         side_guard.side = ix->side_stream;
     }
-    launch_bucket_scans(lq_cnt_of(ix), ix->d_leaf_tile0.as<uint32_t>(), nl, ix->ws_lq_off.as<int64_t>(),
-                        ix->ws_unit_off.as<int64_t>(), d_totals, carried, cap_pairs, cap_units, flags,
-                        ix->ws_lq_cursor.as<uint32_t>(), ls);
+    if (use_bins) {
+        HIPCHECK(ix, ix->ws_bin_units.ensure((size_t)ix->nbins * 8));
+        HIPCHECK(ix, ix->ws_bin_unit_base.ensure((size_t)ix->nbins * 8));
+        BinListParams bl;
+        bl.bin_cursor = (const uint32_t *)(flag_block_of(ix) + BIN_CURSOR_OFF);
+        bl.bin_cap = ix->d_bin_cap.as<uint32_t>(); bl.bin_off = ix->d_bin_off.as<uint32_t>();
+        bl.bin_lo = ix->d_bin_lo.as<uint32_t>();
+        bl.pairs = ix->ws_pairs.as<uint2>();
+        bl.nbins = ix->nbins; bl.nl = nl; bl.nq = nq; bl.stage = ix->opt_list_bins == 2 ? 0 : 1;
+        bl.leaf_tile0 = ix->d_leaf_tile0.as<uint32_t>();
+        bl.cap_pairs = cap_pairs; bl.flags = flags;
+        bl.lq_cnt = lq_cnt_of(ix); bl.lq_off = ix->ws_lq_off.as<int64_t>(); bl.unit_off = ix->ws_unit_off.as<int64_t>();
+        bl.bin_units = ix->ws_bin_units.as<int64_t>(); bl.leaf_queries = ix->ws_leaf_queries.as<int32_t>();
+        launch_bin_lists(bl, ls);
+        launch_bin_prefix(bl.bin_cursor, bl.bin_units, ix->nbins, cap_units, ix->ws_bin_unit_base.as<int64_t>(), d_totals, flags, ls);
+    } else {
+        launch_bucket_scans(lq_cnt_of(ix), ix->d_leaf_tile0.as<uint32_t>(), nl, ix->ws_lq_off.as<int64_t>(),
+                            ix->ws_unit_off.as<int64_t>(), d_totals, carried, cap_pairs, cap_units, flags,
+                            ix->ws_lq_cursor.as<uint32_t>(), ls);
+    }
     int64_t pairs = 0, nunits = 0;
     bool lists_truncated = false;
     if (!carried) {
@@ -1450,6 +1508,27 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
         if (pairs >= (int64_t)0xffffffffll || nunits >= (int64_t)0xffffffffll) return DPF_OK;
     }
     if (!carried) HIPCHECK(ix, ix->ws_leaf_queries.ensure((size_t)std::max<int64_t>(pairs + pairs / 2, 1024) * 4));
+    if (!carried && !lists_truncated && ix->ngran > 0 && ix->opt_list_bins) {
+        // the bins and their regions for the batches to come, cut from this batch's counts
+        ix->bins_seeded = false;
+        HIPCHECK(ix, ix->d_bin_cap.ensure((size_t)BIN_MAX * 4));
+        HIPCHECK(ix, ix->d_bin_off.ensure((size_t)BIN_MAX * 4));
+        HIPCHECK(ix, ix->d_bin_lo.ensure((size_t)(BIN_MAX + 1) * 4));
+        HIPCHECK(ix, ix->d_bin_map.ensure((size_t)ix->ngran * 2));
+        HIPCHECK(ix, ix->d_gran_cnt.ensure((size_t)ix->ngran * 4));
+        unsigned long long *const info = (unsigned long long *)(ix->d_proj_counters + 32);
+        launch_bin_seed(lq_cnt_of(ix), nl, ix->gran_shift, ix->ngran, ix->d_gran_cnt.as<uint32_t>(), ix->d_bin_map.as<uint16_t>(),
+                        ix->d_bin_lo.as<uint32_t>(), ix->d_bin_cap.as<uint32_t>(), ix->d_bin_off.as<uint32_t>(), info, stream);
+        HIPCHECK(ix, hipMemcpyAsync(ix->pinned, info, 16, hipMemcpyDeviceToHost, stream));
+        HIPCHECK(ix, hipStreamSynchronize(stream));
+        const int64_t total_cap = ix->pinned[0], nb = ix->pinned[1];
+        ix->nbins = 0;
+        if (nb > 0 && nb <= BIN_MAX && total_cap < (int64_t)0xffffffffll) {
+            HIPCHECK(ix, ix->ws_pairs.ensure((size_t)total_cap * 8));
+            ix->nbins = (int32_t)nb;
+            ix->bins_seeded = true;
+        }
+    }
     pp.abort = carried ? flags + 3 : nullptr;
     pp.lq_off = ix->ws_lq_off.as<int64_t>();
     pp.lq_cursor = ix->ws_lq_cursor.as<uint32_t>();
@@ -1462,11 +1541,12 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
         HIPCHECK(ix, hipMemsetAsync(ix->ws_lq_cursor.p, 0, (size_t)(nl + 1) * 4, stream));
         launch_probe(2, pp, nq, stream);
     }
-    else launch_fill_lists(pp, nq, ls);
+    else if (!use_bins) launch_fill_lists(pp, nq, ls);
     if (!carried) HIPCHECK(ix, ix->ws_units.ensure((size_t)std::max<int64_t>(nunits + nunits / 2, 1024) * 16));
     launch_units(lq_cnt_of(ix), ix->ws_lq_off.as<int64_t>(), ix->d_leaf_tile0.as<uint32_t>(),
                  (const uint4 *)ix->d_tiles.p, ix->nutiles, ix->ws_unit_off.as<int64_t>(), (uint4 *)ix->ws_units.p,
-                 carried ? flags + 3 : nullptr, ls);
+                 carried ? flags + 3 : nullptr, ls, use_bins ? ix->ws_bin_unit_base.as<int64_t>() : nullptr,
+                 ix->d_bin_map.as<uint16_t>(), ix->gran_shift);
     if (fork) HIPCHECK(ix, hipEventRecord(ix->ev_join, ls));
     if (!lists_truncated) launch_seed_sample(pp, nq, stream);
     if (ix->profiling) HIPCHECK(ix, hipEventRecord(ix->ev[2], stream));
@@ -2157,6 +2237,10 @@ extern "C" int dpf_set_option(dpf_index *ix, int32_t option, int64_t value)
     case DPF_OPT_EXPECTED_ROWS:
         if (value < 0) return fail(ix, DPF_EINVAL, "dpf_set_option: the row count must not be negative");
         ix->opt_expected_rows = value;
+        return DPF_OK;
+    case DPF_OPT_LIST_BINS:
+        if (value < 0 || value > 2) return fail(ix, DPF_EINVAL, "dpf_set_option: list bins must be 0, 1 or 2");
+        ix->opt_list_bins = (int32_t)value;
         return DPF_OK;
     case DPF_OPT_PROBE_LANES:
         if (value < -1 || value > 1) return fail(ix, DPF_EINVAL, "dpf_set_option: probe lanes must be -1 (by the forest), 0 or 1");

@@ -71,7 +71,55 @@ struct ProbeParams {
     // sub-indexes own ^ sub_delta[j]), filled by launch_probe_lanes
     int32_t nsub = 0;
     uint8_t sub_delta[32] = {0};
+    // k_probe_lanes, binned form (bin_cursor != nullptr): the (bucket, query) incidences are not counted into lq_cnt but
+    // written as pairs into the region of the bucket's BIN of pairs[].  A bin is a range of consecutive buckets made of
+    // whole granules (1 << gran_shift buckets; bin_map[bucket >> gran_shift] is the bin), cut so that the bins of the
+    // batch that seeded them held about equally many pairs.  Region b starts at bin_off[b], holds at most bin_cap[b]
+    // pairs, bin_cursor[b] (zeroed) counts what was asked for; *bin_overflow is raised when a region is too small (the
+    // batch is then run again the other way)
+    uint32_t *bin_cursor = nullptr;
+    const uint32_t *bin_cap = nullptr, *bin_off = nullptr;
+    const uint16_t *bin_map = nullptr;
+    uint2 *pairs = nullptr;
+    int32_t gran_shift = 0, nbins = 0;
+    int32_t *bin_overflow = nullptr;
 };
+
+constexpr int BIN_MAX = 1024;              // bins at most
+constexpr int BIN_MAX_LEAVES = 8192;       // buckets of one bin at most
+constexpr int BIN_MAX_GRANULES = 8192;     // granules of a forest at most
+constexpr int BIN_LEAF_BITS = 22;          // a forest with bins has fewer than 1 << 22 buckets
+
+// The bucket lists of a batch from the binned pairs (see ProbeParams): one workgroup per bin builds its buckets' incidence
+// counts, list offsets, unit counts and the lists themselves in LDS.
+struct BinListParams {
+    const uint32_t *bin_cursor, *bin_cap, *bin_off;
+    const uint32_t *bin_lo;           // [nbins + 1] first bucket of each bin
+    const uint2 *pairs;
+    int32_t nbins;
+    int64_t nl;                       // buckets
+    int64_t nq;                       // queries of the batch
+    int32_t stage;                    // 0: the list entries are stored straight to leaf_queries[] (measurement), 1: staged in LDS
+    const uint32_t *leaf_tile0;       // [nl + 1] first tile of each bucket
+    int64_t cap_pairs;                // room in leaf_queries[]
+    int32_t *flags;                   // flags[3]: the batch is abandoned
+    uint32_t *lq_cnt;                 // [nl] out
+    int64_t *lq_off;                  // [nl + 1] out
+    int64_t *unit_off;                // [nl] out: units before the bucket WITHIN its bin
+    int64_t *bin_units;               // [nbins] out: units of each bin
+    int32_t *leaf_queries;            // out
+};
+void launch_bin_lists(const BinListParams &p, hipStream_t stream);
+// bin_unit_base[b] = units of the bins before b; totals[0] = pairs, totals[1] = units; flags[3] raised when the units
+// exceed cap_units
+void launch_bin_prefix(const uint32_t *bin_cursor, const int64_t *bin_units, int32_t nbins, int64_t cap_units, int64_t *bin_unit_base,
+                       int64_t *totals, int32_t *flags, hipStream_t stream);
+// The bins for the batches to come from the incidence counts (lq_cnt) of a batch whose lists were built the other way:
+// granule totals (gran_cnt, scratch of ngran words), then the cut into bins of about equally many pairs and at most
+// BIN_MAX_LEAVES buckets each: bin_map[ngran], bin_lo[bins + 1], the regions' capacities (2 x count + 1024) and offsets;
+// info[0] = the capacities' sum, info[1] = the number of bins (0: more than BIN_MAX, no bins)
+void launch_bin_seed(const uint32_t *lq_cnt, int64_t nl, int32_t gran_shift, int32_t ngran, uint32_t *gran_cnt, uint16_t *bin_map,
+                     uint32_t *bin_lo, uint32_t *bin_cap, uint32_t *bin_off, unsigned long long *info, hipStream_t stream);
 
 // Bucket-major scan: every touched bucket's rows are loaded once and scored
 // against all the queries that probe that bucket.
@@ -171,8 +219,10 @@ void launch_leafscan(int metric, const LeafScanParams &p, hipStream_t stream);
 void launch_bucket_scans(const uint32_t *lq_cnt, const uint32_t *leaf_tile0, int64_t nl, int64_t *lq_off, int64_t *unit_off,
                          int64_t *totals, bool guarded, int64_t cap_pairs, int64_t cap_units, int32_t *flags, uint32_t *lq_off32,
                          hipStream_t stream);
+// (bin_unit_base != nullptr: unit_off[] counts within the bucket's bin and bin_unit_base[bin_map[bucket >> gran_shift]] is added)
 void launch_units(const uint32_t *lq_cnt, const int64_t *lq_off, const uint32_t *leaf_tile0, const uint4 *tiles, int64_t ntiles,
-                  const int64_t *unit_off, uint4 *units, const int32_t *abort, hipStream_t stream);
+                  const int64_t *unit_off, uint4 *units, const int32_t *abort, hipStream_t stream,
+                  const int64_t *bin_unit_base = nullptr, const uint16_t *bin_map = nullptr, int32_t gran_shift = 0);
 void launch_tile_maxnorm(uint4 *tiles, int64_t ntiles, const int32_t *ids, const float *norms, const float *errs, int64_t row_begin,
                          int64_t row_end, float *slot_norms, hipStream_t stream, const uint4 *tails = nullptr, uint4 *slot_tails = nullptr,
                          uint32_t *bounds = nullptr);

@@ -489,25 +489,69 @@ constexpr int PL_THREADS = 256;
 // offsets and incidence counters share cache lines - and the memory pipeline merges the lanes of one instruction
 // that touch one line.  Counted by the finding lane itself, bucket by bucket, every atomic of an instruction went
 // to a line of its own: 380 us instead of 100 on 10k queries over 30 tables.
-template <int NB>   // bits per trie level (dirNodeSize = 1 << NB)
+// BINS: the incidences are not counted into the global histogram (7.7 M returning atomics on c3, which the fabric
+// retires at about 43 G per second) but collected in LDS and written as (bucket, query) pairs into the region of the
+// bucket's bin - a range of consecutive buckets; the bins are cut so that they hold about equally many pairs - with one
+// reservation per (flush, touched bin); k_bin_lists then builds counts, offsets and lists bin by bin in LDS.
+constexpr int PL_MAX_BINS = BIN_MAX;
+constexpr int PL_PAIRS = 3072;                               // pairs a workgroup parks before it writes them out
+template <int NB, bool BINS>   // NB: bits per trie level (dirNodeSize = 1 << NB)
 __global__ __launch_bounds__(PL_THREADS) void k_probe_lanes(ProbeParams p, int64_t nq, int qpw, int T)
 {
     constexpr int PER = NB + 1;                              // buckets a lane can find at one level: NB siblings and its own
+    static_assert(PL_THREADS * PER <= PL_PAIRS, "one level's finds fit the parked pairs");
     __shared__ uint32_t s_nleaf[32];
     __shared__ unsigned long long s_raw[32];
     __shared__ uint32_t s_queue[PL_THREADS * PER];           // bucket | own-bucket flag (bit 31) ...
     __shared__ uint8_t s_queue_q[PL_THREADS * PER];          // ... and the query (of this workgroup's) it belongs to
     __shared__ uint32_t s_qn;
+    __shared__ uint32_t s_pair_leaf[BINS ? PL_PAIRS : 1];    // parked pairs: bucket ...
+    __shared__ uint8_t s_pair_q[BINS ? PL_PAIRS : 1];        // ... and query
+    __shared__ uint32_t s_np;
+    __shared__ uint32_t s_bin_cnt[BINS ? PL_MAX_BINS : 1], s_bin_base[BINS ? PL_MAX_BINS : 1];
     const int tid = threadIdx.x;
     const int64_t q0 = (int64_t)blockIdx.x * qpw;
     const int nql = (int)((nq - q0 < qpw) ? nq - q0 : qpw);
     if (tid < 32) { s_nleaf[tid] = 0; s_raw[tid] = 0; }
-    if (tid == 0) s_qn = 0;
+    if (tid == 0) { s_qn = 0; s_np = 0; }
     __syncthreads();
     const int P = 1 << p.pb;
     constexpr uint32_t mask = (1u << NB) - 1u;
     constexpr int dns = 1 << NB;
     const int trie_bits = (p.max_level + 1) * NB;
+    // (BINS) the parked pairs into their bins' regions: count per bin, one reservation per touched bin, place
+    auto flush_pairs = [&]() {
+        if constexpr (BINS) {
+            const uint32_t np = s_np;
+            if (np == 0) return;                             // (uniform)
+            for (int b = tid; b < p.nbins; b += PL_THREADS) s_bin_cnt[b] = 0;
+            __syncthreads();
+            for (uint32_t e = tid; e < np; e += PL_THREADS) {    // (the bin rides in the bits above the bucket number)
+                const uint32_t leaf = s_pair_leaf[e], b = p.bin_map[leaf >> p.gran_shift];
+                s_pair_leaf[e] = leaf | (b << BIN_LEAF_BITS);
+                atomicAdd(&s_bin_cnt[b], 1u);
+            }
+            __syncthreads();
+            for (int b = tid; b < p.nbins; b += PL_THREADS) {
+                const uint32_t c = s_bin_cnt[b];
+                if (c) {
+                    const uint32_t base = atomicAdd(&p.bin_cursor[b], c);
+                    s_bin_base[b] = base;
+                    if (base + c > p.bin_cap[b]) *p.bin_overflow = 1;
+                    s_bin_cnt[b] = 0;
+                }
+            }
+            __syncthreads();
+            for (uint32_t e = tid; e < np; e += PL_THREADS) {
+                const uint32_t w = s_pair_leaf[e], leaf = w & ((1u << BIN_LEAF_BITS) - 1u), b = w >> BIN_LEAF_BITS;
+                const uint32_t at = s_bin_base[b] + atomicAdd(&s_bin_cnt[b], 1u);
+                if (at < p.bin_cap[b]) p.pairs[(size_t)p.bin_off[b] + at] = make_uint2(leaf, (uint32_t)(q0 + s_pair_q[e]));
+            }
+            __syncthreads();
+            if (tid == 0) s_np = 0;
+            __syncthreads();
+        }
+    };
     for (int x0 = 0; x0 < nql * T; x0 += PL_THREADS) {       // (uniform over the workgroup: barriers inside)
         const int x = x0 + tid;
         const bool live = x < nql * T;
@@ -582,6 +626,9 @@ __global__ __launch_bounds__(PL_THREADS) void k_probe_lanes(ProbeParams p, int64
             __syncthreads();
             // every lane counts one queue entry at a time
             const uint32_t n = s_qn;
+            if constexpr (BINS) {
+                if (s_np + n > (uint32_t)PL_PAIRS) flush_pairs();     // (uniform: both numbers are the workgroup's)
+            }
             for (uint32_t e = tid; e < n; e += PL_THREADS) {
                 const uint32_t ent = s_queue[e], leaf = ent & 0x7fffffffu;
                 const int eq = s_queue_q[e];
@@ -591,11 +638,18 @@ __global__ __launch_bounds__(PL_THREADS) void k_probe_lanes(ProbeParams p, int64
                 const uint32_t lb = p.leaf_off[leaf], le = p.leaf_off[leaf + 1];
 #endif
                 if (le > lb) {
+                    uint32_t place = 0;
+                    if constexpr (BINS) {
+                        const uint32_t at = atomicAdd(&s_np, 1u);
+                        s_pair_leaf[at] = leaf;
+                        s_pair_q[at] = (uint8_t)eq;
+                    } else {
 #if defined(DPF_PROBE_ABLATE) && (DPF_PROBE_ABLATE & 1)
-                    const uint32_t place = leaf == 0xfffffff0u ? atomicAdd(&p.lq_cnt[0], 1u) : 0u;
+                        place = leaf == 0xfffffff0u ? atomicAdd(&p.lq_cnt[0], 1u) : 0u;
 #else
-                    const uint32_t place = atomicAdd(&p.lq_cnt[leaf], 1u);
+                        place = atomicAdd(&p.lq_cnt[leaf], 1u);
 #endif
+                    }
                     const uint32_t pos = atomicAdd(&s_nleaf[eq], 1u);
                     atomicAdd(&s_raw[eq], (unsigned long long)(le - lb));
                     // top bit: the bucket the query itself would be stored in (own sub-index, own path)
@@ -609,6 +663,7 @@ __global__ __launch_bounds__(PL_THREADS) void k_probe_lanes(ProbeParams p, int64
         __syncthreads();
     }
     __syncthreads();
+    flush_pairs();
     const int64_t range = p.row_end - p.row_begin;
     if (tid < nql) {
         const int64_t q = q0 + tid;
@@ -627,7 +682,9 @@ __global__ __launch_bounds__(PL_THREADS) void k_probe_lanes(ProbeParams p, int64
 bool launch_probe_lanes(ProbeParams p, int64_t nq, hipStream_t stream)
 {
     if (nq <= 0) return true;
-    if (!p.lq_cnt || !p.q_leaves || p.nbits < 5 || p.nbits > 8 || p.dns != (1 << p.nbits) || p.pb > 5) return false;
+    if (!p.q_leaves || p.nbits < 5 || p.nbits > 8 || p.dns != (1 << p.nbits) || p.pb > 5) return false;
+    const bool bins = p.bin_cursor != nullptr;
+    if (bins ? (p.nbins < 1 || p.nbins > PL_MAX_BINS || !p.pairs || !p.bin_cap || !p.bin_off || !p.bin_overflow) : !p.lq_cnt) return false;
     p.nsub = 0;
     for (int d = 0; d < (1 << p.pb); d++)
         if (__builtin_popcount((unsigned)d) <= p.steps) p.sub_delta[p.nsub++] = (uint8_t)d;
@@ -639,12 +696,18 @@ bool launch_probe_lanes(ProbeParams p, int64_t nq, hipStream_t stream)
     if (qpw < 1) qpw = 1;
     if (qpw > 32) qpw = 32;
     const int64_t grid = (nq + qpw - 1) / qpw;
+#define DPF_PL(NB)                                                                                                      \
+    do {                                                                                                                \
+        if (bins) hipLaunchKernelGGL((k_probe_lanes<NB, true>), dim3((unsigned)grid), dim3(PL_THREADS), 0, stream, p, nq, qpw, T); \
+        else hipLaunchKernelGGL((k_probe_lanes<NB, false>), dim3((unsigned)grid), dim3(PL_THREADS), 0, stream, p, nq, qpw, T);     \
+    } while (0)
     switch (p.nbits) {
-    case 5: hipLaunchKernelGGL((k_probe_lanes<5>), dim3((unsigned)grid), dim3(PL_THREADS), 0, stream, p, nq, qpw, T); break;
-    case 6: hipLaunchKernelGGL((k_probe_lanes<6>), dim3((unsigned)grid), dim3(PL_THREADS), 0, stream, p, nq, qpw, T); break;
-    case 7: hipLaunchKernelGGL((k_probe_lanes<7>), dim3((unsigned)grid), dim3(PL_THREADS), 0, stream, p, nq, qpw, T); break;
-    default: hipLaunchKernelGGL((k_probe_lanes<8>), dim3((unsigned)grid), dim3(PL_THREADS), 0, stream, p, nq, qpw, T); break;
+    case 5: DPF_PL(5); break;
+    case 6: DPF_PL(6); break;
+    case 7: DPF_PL(7); break;
+    default: DPF_PL(8); break;
     }
+#undef DPF_PL
     return true;
 }
 
@@ -1362,11 +1425,256 @@ void launch_bucket_scans(const uint32_t *lq_cnt, const uint32_t *leaf_tile0, int
     if (ntiles > 0) hipLaunchKernelGGL(k_scan2_apply, dim3((unsigned)ntiles), dim3(SCAN_THREADS), 0, stream, lq_cnt, leaf_tile0, nl, lq_off, unit_off, lq_off32);
 }
 
+// ---------------------------------------------------------------------------
+// k_bin_lists: one workgroup per bin of buckets.  The bin's (bucket, query) pairs (k_probe_lanes, binned form) give,
+// all in LDS: the buckets' incidence counts, their exclusive scan (list offsets, on top of the pairs of the bins
+// before), the buckets' work-unit counts and their scan, and the place of every pair in its bucket's list.
+// A compute unit retires about one lane of scattered LDS atomics or 4-byte stores per cycle, so a workgroup's time is
+// its bin's pairs: the bins are cut to hold about equally many (k_bin_seed).
+// ---------------------------------------------------------------------------
+constexpr int BL_THREADS = 1024;
+constexpr int BL_UNROLL = 8;                                 // pairs per thread in flight
+constexpr int BL_STAGE = 64000;                              // list entries (16-bit query numbers) a workgroup stages in LDS
+constexpr size_t BL_LDS = (size_t)BIN_MAX_LEAVES * 4 + (size_t)BL_STAGE * 2;
+static_assert(BL_STAGE * 2 >= BIN_MAX_LEAVES * 4, "the staging area also holds one word per bucket");
+__global__ __launch_bounds__(BL_THREADS) void k_bin_lists(BinListParams p)
+{
+    extern __shared__ uint32_t s_bl[];
+    uint32_t *const s_cnt = s_bl;                            // incidences of each bucket, then its fill cursor
+    uint32_t *const s_word = s_bl + BIN_MAX_LEAVES;          // the staging area as words (unit offsets of the buckets) ...
+    uint16_t *const s_stage = (uint16_t *)s_word;            // ... and as the bin's list entries
+    __shared__ unsigned long long s_red[BL_THREADS / 64][2];
+    __shared__ uint32_t s_wave[BL_THREADS / 64][2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x;
+    if (p.flags[3]) return;                                  // a bin's region was too small: the batch is run again
+    // pairs of all bins, and of the bins before this one
+    unsigned long long tot = 0, before = 0;
+    for (int i = tid; i < p.nbins; i += BL_THREADS) {
+        const unsigned long long c = p.bin_cursor[i];
+        tot += c;
+        if (i < b) before += c;
+    }
+    for (int o = 32; o > 0; o >>= 1) { tot += __shfl_xor(tot, o); before += __shfl_xor(before, o); }
+    if (lane == 0) { s_red[wave][0] = tot; s_red[wave][1] = before; }
+    __syncthreads();
+    tot = 0; before = 0;
+    for (int w = 0; w < BL_THREADS / 64; w++) { tot += s_red[w][0]; before += s_red[w][1]; }
+    if (tot > (unsigned long long)p.cap_pairs) {             // leaf_queries[] has no room (every workgroup sees the same)
+        if (b == 0 && tid == 0) p.flags[3] = 1;
+        return;
+    }
+    const uint32_t leaf0 = p.bin_lo[b];
+    const uint32_t nleaf = min(p.bin_lo[b + 1] - leaf0, (uint32_t)BIN_MAX_LEAVES);
+    const uint32_t n = p.bin_cursor[b];
+    const uint2 *src = p.pairs + p.bin_off[b];
+    for (uint32_t i = tid; i < (uint32_t)BIN_MAX_LEAVES; i += BL_THREADS) s_cnt[i] = 0;
+    __syncthreads();
+    // (several pairs per thread in flight: a workgroup has little else to hide the loads behind)
+    for (uint32_t i0 = tid; i0 < n; i0 += BL_UNROLL * BL_THREADS) {
+        uint32_t lf[BL_UNROLL];
+#pragma unroll
+        for (int u = 0; u < BL_UNROLL; u++) lf[u] = i0 + u * BL_THREADS < n ? src[i0 + u * BL_THREADS].x - leaf0 : 0xffffffffu;
+#pragma unroll
+        for (int u = 0; u < BL_UNROLL; u++)
+            if (lf[u] < nleaf) atomicAdd(&s_cnt[lf[u]], 1u);
+    }
+    __syncthreads();
+    // exclusive scans over the bin's buckets: incidences and work units; thread t owns BIN_MAX_LEAVES / BL_THREADS buckets
+    constexpr uint32_t per = BIN_MAX_LEAVES / BL_THREADS;
+    const uint32_t l0 = tid * per;
+    uint32_t cn[per], un[per];
+    uint32_t sa = 0, su = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < per; j++) {
+        const uint32_t l = l0 + j;
+        cn[j] = 0; un[j] = 0;
+        if (l < nleaf) {
+            cn[j] = s_cnt[l];
+            un[j] = units_of_leaf(cn[j], p.leaf_tile0[leaf0 + l + 1] - p.leaf_tile0[leaf0 + l]);
+        }
+        sa += cn[j]; su += un[j];
+    }
+    uint32_t ia = sa, iu = su;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t ua = __shfl_up(ia, o), uu = __shfl_up(iu, o);
+        if (lane >= o) { ia += ua; iu += uu; }
+    }
+    if (lane == 63) { s_wave[wave][0] = ia; s_wave[wave][1] = iu; }
+    __syncthreads();
+    uint32_t ra = ia - sa, ru = iu - su, all_u = 0;
+    for (int w = 0; w < BL_THREADS / 64; w++) {
+        if (w < wave) { ra += s_wave[w][0]; ru += s_wave[w][1]; }
+        all_u += s_wave[w][1];
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < per; j++) {
+        const uint32_t l = l0 + j;
+        if (l < nleaf) {
+            s_cnt[l] = ra;                                   // (from here on: where the bucket's next list entry goes)
+            s_word[l] = ru;
+        }
+        ra += cn[j]; ru += un[j];
+    }
+    if (tid == 0) {
+        p.bin_units[b] = (int64_t)all_u;
+        if (b == p.nbins - 1) p.lq_off[p.nl] = (int64_t)tot;
+    }
+    __syncthreads();
+    for (uint32_t l = tid; l < nleaf; l += BL_THREADS) p.unit_off[leaf0 + l] = (int64_t)s_word[l];
+    __syncthreads();
+    // The lists.  A compute unit retires a scattered 4-byte store every other cycle, so the entries are put in place in
+    // LDS and written out in order, whole lines at a time; a bin that outgrew the staging area (or query numbers past 16
+    // bits) is placed in global memory directly.
+    int32_t *out = p.leaf_queries + before;
+    const bool staged = p.stage && n <= (uint32_t)BL_STAGE && p.nq <= 65536;
+    for (uint32_t i0 = tid; i0 < n; i0 += BL_UNROLL * BL_THREADS) {
+        uint2 e[BL_UNROLL];
+#pragma unroll
+        for (int u = 0; u < BL_UNROLL; u++) e[u] = i0 + u * BL_THREADS < n ? src[i0 + u * BL_THREADS] : make_uint2(0xffffffffu, 0u);
+#pragma unroll
+        for (int u = 0; u < BL_UNROLL; u++) {
+            const uint32_t l = e[u].x - leaf0;
+            if (e[u].x != 0xffffffffu && l < nleaf) {
+                const uint32_t at = atomicAdd(&s_cnt[l], 1u);
+                if (staged) s_stage[at] = (uint16_t)e[u].y;
+                else out[at] = (int32_t)e[u].y;
+            }
+        }
+    }
+    __syncthreads();
+    if (staged)
+        for (uint32_t i = tid; i < n; i += BL_THREADS) out[i] = (int32_t)s_stage[i];
+    // (every cursor now stands at its bucket's end = the next bucket's start)
+    for (uint32_t l = tid; l < nleaf; l += BL_THREADS) {
+        const uint32_t lo = l ? s_cnt[l - 1] : 0u;
+        p.lq_cnt[leaf0 + l] = s_cnt[l] - lo;
+        p.lq_off[leaf0 + l] = (int64_t)(before + lo);
+    }
+}
+
+void launch_bin_lists(const BinListParams &p, hipStream_t stream)
+{
+    if (p.nbins > 0) hipLaunchKernelGGL(k_bin_lists, dim3((unsigned)p.nbins), dim3(BL_THREADS), BL_LDS, stream, p);
+}
+
+__global__ __launch_bounds__(1024) void k_bin_prefix(const uint32_t *__restrict__ bin_cursor, const int64_t *__restrict__ bin_units, int nbins,
+                                                     int64_t cap_units, int64_t *__restrict__ bin_unit_base, int64_t *__restrict__ totals,
+                                                     int32_t *__restrict__ flags)
+{
+    __shared__ long long part[1024];
+    __shared__ long long pairs[1024];
+    const int tid = threadIdx.x;
+    if (flags[3]) return;
+    const long long v = tid < nbins ? bin_units[tid] : 0;
+    part[tid] = v;
+    pairs[tid] = tid < nbins ? (long long)bin_cursor[tid] : 0;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const long long a = tid >= o ? part[tid - o] : 0, c = tid >= o ? pairs[tid - o] : 0;
+        __syncthreads();
+        part[tid] += a; pairs[tid] += c;
+        __syncthreads();
+    }
+    if (tid < nbins) bin_unit_base[tid] = part[tid] - v;
+    if (tid == 1023) {
+        totals[0] = pairs[1023];
+        totals[1] = part[1023];
+        if (part[1023] > cap_units) flags[3] = 1;
+    }
+}
+
+void launch_bin_prefix(const uint32_t *bin_cursor, const int64_t *bin_units, int32_t nbins, int64_t cap_units, int64_t *bin_unit_base,
+                       int64_t *totals, int32_t *flags, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_bin_prefix, dim3(1), dim3(1024), 0, stream, bin_cursor, bin_units, (int)nbins, cap_units, bin_unit_base, totals, flags);
+}
+
+// the incidences of every granule of buckets of a batch (counted into lq_cnt): a wave per granule
+__global__ __launch_bounds__(256) void k_bin_granules(const uint32_t *__restrict__ lq_cnt, int64_t nl, int gran_shift, int ngran,
+                                                      uint32_t *__restrict__ gran_cnt)
+{
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (g >= ngran) return;
+    const int64_t l0 = (int64_t)g << gran_shift, l1 = min(nl, l0 + ((int64_t)1 << gran_shift));
+    uint32_t c = 0;
+    for (int64_t l = l0 + lane; l < l1; l += 64) c += lq_cnt[l];
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if (lane == 0) gran_cnt[g] = c;
+}
+
+// One workgroup: the cut of the granules into bins.  A bin is closed when the next granule would take it past the target
+// or past BIN_MAX_LEAVES buckets; one thread walks the granules (a few thousand steps over LDS, in a batch that waits for
+// the host anyway), the others load and store.  The target: the batch's incidences / 224 (a bin for nearly every compute
+// unit), but no more than half of what k_bin_lists stages in LDS (a later batch may bring twice as many) - unless that
+// made more than about 700 bins.
+__global__ __launch_bounds__(1024) void k_bin_seed(const uint32_t *__restrict__ gran_cnt, int64_t nl, int gran_shift, int ngran,
+                                                   uint16_t *__restrict__ bin_map, uint32_t *__restrict__ bin_lo,
+                                                   uint32_t *__restrict__ bin_cap, uint32_t *__restrict__ bin_off,
+                                                   unsigned long long *__restrict__ info)
+{
+    __shared__ uint32_t s_g[BIN_MAX_GRANULES];
+    __shared__ uint16_t s_map[BIN_MAX_GRANULES];
+    __shared__ uint32_t s_lo[BIN_MAX + 1], s_pairs[BIN_MAX];
+    __shared__ unsigned long long s_red[16];
+    __shared__ int s_nb;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned long long sum = 0;
+    for (int g = tid; g < ngran; g += 1024) { const uint32_t c = gran_cnt[g]; s_g[g] = c; sum += c; }
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if (lane == 0) s_red[wave] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long total = 0;
+        for (int w = 0; w < 16; w++) total += s_red[w];
+        unsigned long long target = max(total / 224ull, 1024ull);
+        if (target > (unsigned long long)BL_STAGE / 2) target = max((unsigned long long)BL_STAGE / 2, total / 700ull);
+        const int max_gran = BIN_MAX_LEAVES >> gran_shift;
+        int nb = 0, in_bin = 0;
+        unsigned long long acc = 0;
+        for (int g = 0; g < ngran; g++) {
+            const uint32_t c = s_g[g];
+            if (in_bin > 0 && (acc + c > target || in_bin == max_gran)) {
+                if (nb < BIN_MAX) s_pairs[nb] = (uint32_t)min(acc, 0x7fffffffull);
+                nb++; acc = 0; in_bin = 0;
+            }
+            if (in_bin == 0 && nb < BIN_MAX) s_lo[nb] = (uint32_t)g << gran_shift;
+            s_map[g] = (uint16_t)min(nb, BIN_MAX - 1);
+            acc += c; in_bin++;
+        }
+        if (in_bin > 0) { if (nb < BIN_MAX) s_pairs[nb] = (uint32_t)min(acc, 0x7fffffffull); nb++; }
+        if (nb > BIN_MAX) nb = 0;                            // (no bins: the lists are built the other way)
+        else s_lo[nb] = (uint32_t)nl;
+        s_nb = nb;
+        unsigned long long off = 0;
+        for (int i = 0; i < nb; i++) {
+            const unsigned long long cap = 2ull * s_pairs[i] + 1024ull;
+            bin_cap[i] = (uint32_t)min(cap, 0xffffffffull);
+            bin_off[i] = (uint32_t)min(off, 0xffffffffull);
+            off += cap;
+        }
+        info[0] = off;
+        info[1] = (unsigned long long)nb;
+    }
+    __syncthreads();
+    const int nb = s_nb;
+    for (int g = tid; g < ngran; g += 1024) bin_map[g] = s_map[g];
+    for (int i = tid; i <= nb && nb > 0; i += 1024) bin_lo[i] = s_lo[i];
+}
+
+void launch_bin_seed(const uint32_t *lq_cnt, int64_t nl, int32_t gran_shift, int32_t ngran, uint32_t *gran_cnt, uint16_t *bin_map,
+                     uint32_t *bin_lo, uint32_t *bin_cap, uint32_t *bin_off, unsigned long long *info, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_bin_granules, dim3((unsigned)((ngran + 3) / 4)), dim3(256), 0, stream, lq_cnt, nl, (int)gran_shift, (int)ngran, gran_cnt);
+    hipLaunchKernelGGL(k_bin_seed, dim3(1), dim3(1024), 0, stream, gran_cnt, nl, (int)gran_shift, (int)ngran, bin_map, bin_lo, bin_cap, bin_off, info);
+}
+
 // one thread per tile (a long bucket has thousands of them)
 __global__ __launch_bounds__(256) void k_units(const uint32_t *__restrict__ lq_cnt, const int64_t *__restrict__ lq_off,
                                                const uint32_t *__restrict__ leaf_tile0, const uint4 *__restrict__ tiles,
                                                int64_t ntiles, const int64_t *__restrict__ unit_off, uint4 *__restrict__ units,
-                                               const int32_t *__restrict__ abort)
+                                               const int32_t *__restrict__ abort, const int64_t *__restrict__ bin_unit_base,
+                                               const uint16_t *__restrict__ bin_map, int gran_shift)
 {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= ntiles || (abort && *abort)) return;
@@ -1375,6 +1683,7 @@ __global__ __launch_bounds__(256) void k_units(const uint32_t *__restrict__ lq_c
     if (cnt == 0) return;
     const uint32_t groups = (cnt + UNIT_QUERIES - 1u) / UNIT_QUERIES;
     int64_t base = unit_off[l] + (int64_t)((uint32_t)t - leaf_tile0[l]) * groups;
+    if (bin_unit_base) base += bin_unit_base[bin_map[l >> gran_shift]];
     const uint32_t lqb = (uint32_t)lq_off[l];
     for (uint32_t c = 0; c < cnt; c += UNIT_QUERIES)
         units[base++] = make_uint4(td.y, td.z | (min(UNIT_QUERIES, cnt - c) << 8), lqb + c, td.w);
@@ -1446,9 +1755,12 @@ __global__ __launch_bounds__(256) void k_tile_maxnorm(uint4 *__restrict__ tiles,
 }
 
 void launch_units(const uint32_t *lq_cnt, const int64_t *lq_off, const uint32_t *leaf_tile0, const uint4 *tiles, int64_t ntiles,
-                  const int64_t *unit_off, uint4 *units, const int32_t *abort, hipStream_t stream)
+                  const int64_t *unit_off, uint4 *units, const int32_t *abort, hipStream_t stream, const int64_t *bin_unit_base,
+                  const uint16_t *bin_map, int32_t gran_shift)
 {
-    if (ntiles > 0) hipLaunchKernelGGL(k_units, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, stream, lq_cnt, lq_off, leaf_tile0, tiles, ntiles, unit_off, units, abort);
+    if (ntiles > 0)
+        hipLaunchKernelGGL(k_units, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, stream, lq_cnt, lq_off, leaf_tile0, tiles, ntiles,
+                           unit_off, units, abort, bin_unit_base, bin_map, (int)gran_shift);
 }
 void launch_tile_maxnorm(uint4 *tiles, int64_t ntiles, const int32_t *ids, const float *norms, const float *errs, int64_t row_begin,
                          int64_t row_end, float *slot_norms, hipStream_t stream, const uint4 *tails, uint4 *slot_tails, uint32_t *bounds)
@@ -2904,6 +3216,8 @@ int configure_kernels()
         }
     }
     e = hipFuncSetAttribute((const void *)k_unique_lists, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds - 1024);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void *)k_bin_lists, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BL_LDS);
     if (e != hipSuccess) return (int)e;
     return 0;
 }

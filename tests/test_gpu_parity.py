@@ -558,13 +558,16 @@ def test_list_sizes_carried_from_batch_to_batch(metric):
 
 
 @pytest.mark.gpu
-def test_carried_sizes_with_a_truncated_bucket_list():
+@pytest.mark.parametrize("bins", [0, 1, 2])
+def test_carried_sizes_with_a_truncated_bucket_list(bins):
     # a batch that did not wait for its sizes and then truncates a query's bucket list is run again
-    # with the second walk
+    # with the second walk - when the lists are filled from the remembered buckets (list_bins = 0); built from the binned
+    # (bucket, query) pairs they do not depend on the remembered buckets, which then only feed the seed sample
     params, X, Q, pick = make_problem(n=8000, nq=60, bucket_overflow=60, n_clusters=6, table_num=2, permutation_num=1)
     slow = DpfIndex(dict(params, flags=2), metric="l2")
     slow.fit(X)
     fast = DpfIndex(params, metric="l2")
+    fast.set_option("list_bins", bins)
     fast.fit(X)
     seen = []
     for i, steps in enumerate((1, 1, 1, 1, 0)):
@@ -576,7 +579,51 @@ def test_carried_sizes_with_a_truncated_bucket_list():
         seen.append(st["last_sizes_carried"])
         want = slow.query_topk(pick, Q, steps=steps, k=10)
         assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1], equal_nan=True), (steps, seen)
-    assert seen[:4] == [0, 1, 2, 0], seen
+    assert seen[:4] == ([0, 1, 1, 1] if bins else [0, 1, 2, 0]), seen
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bins", [1, 2])
+def test_binned_lists_when_the_queries_move(bins):
+    # The bins of buckets and their regions are cut from the batch that was sized on the host.  A later batch of many
+    # more, and other, queries outgrows the regions: it is run again with its sizes read back, which cuts the bins
+    # anew, and the batches after it are carried again.  Same answers as the query-major path throughout.
+    params, X, Q, pick = make_problem(n=20000, nq=1500, bucket_overflow=40, n_clusters=40, table_num=3, permutation_num=2)
+    slow = DpfIndex(dict(params, flags=2), metric="l2")
+    slow.fit(X)
+    fast = DpfIndex(params, metric="l2")
+    fast.set_option("list_bins", bins)
+    fast.fit(X)
+    seen = []
+    for lo, hi in ((0, 20), (0, 20), (20, 1500), (20, 1500), (700, 760), (0, 1500)):
+        got = fast.query_topk(pick[lo:hi], Q[lo:hi], steps=1, k=10)
+        st = fast.stats()
+        assert st["last_path"] == 1
+        seen.append(st["last_sizes_carried"])
+        want = slow.query_topk(pick[lo:hi], Q[lo:hi], steps=1, k=10)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1], equal_nan=True), ((lo, hi), seen)
+    assert seen == [0, 1, 2, 1, 1, 1], seen
+
+
+@pytest.mark.gpu
+def test_binned_lists_with_query_numbers_past_16_bits():
+    # the list entries are staged in LDS as 16-bit query numbers; a batch of more than 65536 queries is not staged
+    params, X, Q, pick = make_problem(n=6000, nq=200, dim=32, bucket_overflow=40, n_clusters=20, table_num=2, permutation_num=1)
+    reps = 66000 // 200 + 1
+    Qb = np.ascontiguousarray(np.tile(Q, (reps, 1)))
+    pb = np.ascontiguousarray(np.tile(pick, reps))
+    fast = DpfIndex(params, metric="l2")
+    fast.fit(X)
+    first = fast.query_topk(pb, Qb, steps=1, k=5)
+    again = fast.query_topk(pb, Qb, steps=1, k=5)
+    assert fast.stats()["last_path"] == 1 and fast.stats()["last_sizes_carried"] == 1
+    assert np.array_equal(first[0], again[0]) and np.array_equal(first[1], again[1], equal_nan=True)
+    slow = DpfIndex(dict(params, flags=2), metric="l2")
+    slow.fit(X)
+    want = slow.query_topk(pick, Q, steps=1, k=5)
+    for r in (0, reps - 1):
+        assert np.array_equal(again[0][r * 200:(r + 1) * 200], want[0])
+        assert np.array_equal(again[1][r * 200:(r + 1) * 200], want[1], equal_nan=True)
 
 
 @pytest.mark.gpu
