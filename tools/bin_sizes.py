@@ -21,6 +21,8 @@ pad = np.zeros(((nl + G - 1) // G) * G, dtype=np.int64)
 pad[:nl] = bc
 gran = pad.reshape(-1, G).sum(1)
 target = max(int(gran.sum()) // 224, 1024)
+if target > 32000:                     # (half of what k_bin_lists stages in LDS, unless that made more than about 700 bins)
+    target = max(32000, int(gran.sum()) // 700)
 max_gran = 8192 >> shift
 bins, acc, n_in = [], 0, 0
 for c in gran:
