@@ -899,6 +899,15 @@ def test_random_configurations(seed, dims=(8, 33, 64, 100, 130, 256)):
     assert_same_sets(fast.query_batch(pick, Q, steps=steps), (off, ids))
     want = orc.topk(Q64, off, ids, k=k, metric=metric)
     assert_topk_equal(fi, fs, want[0], want[1])
+    # the handle's later batches do not wait for their list sizes and build the bucket lists from binned pairs: other
+    # queries, other step counts, same answers as the gather path
+    for rep in range(3):
+        steps2 = int(rng.randint(0, pb + 1))
+        sel = rng.permutation(len(pick))[:max(1, len(pick) - 7 * rep)]
+        qi, qq = np.ascontiguousarray(pick[sel]), np.ascontiguousarray(Q[sel])
+        fi2, fs2 = fast.query_topk(qi, qq, steps=steps2, k=k)
+        si2, ss2 = slow.query_topk(qi, qq, steps=steps2, k=k)
+        assert np.array_equal(fi2, si2) and np.array_equal(fs2, ss2, equal_nan=True), (rep, steps2, fast.stats()["last_sizes_carried"])
 
 
 @pytest.mark.gpu
