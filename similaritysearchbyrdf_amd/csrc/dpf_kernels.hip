@@ -1603,63 +1603,107 @@ __global__ __launch_bounds__(256) void k_bin_granules(const uint32_t *__restrict
     if (lane == 0) gran_cnt[g] = c;
 }
 
-// One workgroup: the cut of the granules into bins.  A bin is closed when the next granule would take it past the target
-// or past BIN_MAX_LEAVES buckets; one thread walks the granules (a few thousand steps over LDS, in a batch that waits for
-// the host anyway), the others load and store.  The target: the batch's incidences / 224 (a bin for nearly every compute
-// unit), but no more than half of what k_bin_lists stages in LDS (a later batch may bring twice as many) - unless that
-// made more than about 700 bins.
+// One workgroup: the cut of the granules into bins.  With e(g) = the pairs of the granules before g, granule g gets the
+// key e(g) / target, a run of granules with one key is cut every BIN_MAX_LEAVES buckets, and every piece is a bin: a bin
+// holds at most target pairs and one granule's more (a granule larger than the target has a key to itself).  The target:
+// the batch's incidences / 224 (a bin for nearly every compute unit), but no more than half of what k_bin_lists stages in
+// LDS (a later batch may bring twice as many) - unless that made more than about 700 bins.  Three scans over the granules
+// (pairs, start of the key's run, pieces), each thread owning eight consecutive granules, and one over the bins.
 __global__ __launch_bounds__(1024) void k_bin_seed(const uint32_t *__restrict__ gran_cnt, int64_t nl, int gran_shift, int ngran,
                                                    uint16_t *__restrict__ bin_map, uint32_t *__restrict__ bin_lo,
                                                    uint32_t *__restrict__ bin_cap, uint32_t *__restrict__ bin_off,
                                                    unsigned long long *__restrict__ info)
 {
-    __shared__ uint32_t s_g[BIN_MAX_GRANULES];
-    __shared__ uint16_t s_map[BIN_MAX_GRANULES];
-    __shared__ uint32_t s_lo[BIN_MAX + 1], s_pairs[BIN_MAX];
-    __shared__ unsigned long long s_red[16];
-    __shared__ int s_nb;
+    constexpr int PER = BIN_MAX_GRANULES / 1024;
+    static_assert(BIN_MAX <= 1024, "one bin per thread in the last scan");
+    __shared__ unsigned long long s_w[16];
+    __shared__ uint32_t s_pairs[BIN_MAX], s_lo[BIN_MAX];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    unsigned long long sum = 0;
-    for (int g = tid; g < ngran; g += 1024) { const uint32_t c = gran_cnt[g]; s_g[g] = c; sum += c; }
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-    if (lane == 0) s_red[wave] = sum;
-    __syncthreads();
-    if (tid == 0) {
-        unsigned long long total = 0;
-        for (int w = 0; w < 16; w++) total += s_red[w];
-        unsigned long long target = max(total / 224ull, 1024ull);
-        if (target > (unsigned long long)BL_STAGE / 2) target = max((unsigned long long)BL_STAGE / 2, total / 700ull);
-        const int max_gran = BIN_MAX_LEAVES >> gran_shift;
-        int nb = 0, in_bin = 0;
-        unsigned long long acc = 0;
-        for (int g = 0; g < ngran; g++) {
-            const uint32_t c = s_g[g];
-            if (in_bin > 0 && (acc + c > target || in_bin == max_gran)) {
-                if (nb < BIN_MAX) s_pairs[nb] = (uint32_t)min(acc, 0x7fffffffull);
-                nb++; acc = 0; in_bin = 0;
-            }
-            if (in_bin == 0 && nb < BIN_MAX) s_lo[nb] = (uint32_t)g << gran_shift;
-            s_map[g] = (uint16_t)min(nb, BIN_MAX - 1);
-            acc += c; in_bin++;
+    // exclusive scan over the workgroup's threads, sum or maximum; `all` = over every thread
+    auto scan = [&](unsigned long long v, bool take_max, unsigned long long &all) {
+        unsigned long long in = v;
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned long long u = __shfl_up(in, o);
+            if (lane >= o) in = take_max ? max(in, u) : in + u;
         }
-        if (in_bin > 0) { if (nb < BIN_MAX) s_pairs[nb] = (uint32_t)min(acc, 0x7fffffffull); nb++; }
-        if (nb > BIN_MAX) nb = 0;                            // (no bins: the lists are built the other way)
-        else s_lo[nb] = (uint32_t)nl;
-        s_nb = nb;
-        unsigned long long off = 0;
-        for (int i = 0; i < nb; i++) {
-            const unsigned long long cap = 2ull * s_pairs[i] + 1024ull;
-            bin_cap[i] = (uint32_t)min(cap, 0xffffffffull);
-            bin_off[i] = (uint32_t)min(off, 0xffffffffull);
-            off += cap;
+        __syncthreads();                                     // (s_w may still be read from the scan before)
+        if (lane == 63) s_w[wave] = in;
+        __syncthreads();
+        unsigned long long before = 0;
+        all = 0;
+        for (int w = 0; w < 16; w++) {
+            if (w < wave) before = take_max ? max(before, s_w[w]) : before + s_w[w];
+            all = take_max ? max(all, s_w[w]) : all + s_w[w];
         }
-        info[0] = off;
-        info[1] = (unsigned long long)nb;
+        const unsigned long long prev = __shfl_up(in, 1);    // inclusive value of the lane before
+        if (lane == 0) return before;
+        return take_max ? max(before, prev) : before + prev;
+    };
+    for (int i = tid; i < BIN_MAX; i += 1024) { s_pairs[i] = 0; s_lo[i] = 0; }
+    const int g0 = tid * PER;
+    uint32_t c[PER];
+    unsigned long long mine = 0;
+#pragma unroll
+    for (int j = 0; j < PER; j++) { c[j] = g0 + j < ngran ? gran_cnt[g0 + j] : 0u; mine += c[j]; }
+    unsigned long long total;
+    unsigned long long e = scan(mine, false, total);         // pairs before this thread's first granule
+    unsigned long long target = max(total / 224ull, 1024ull);
+    if (target > (unsigned long long)BL_STAGE / 2) target = max((unsigned long long)BL_STAGE / 2, total / 700ull);
+    const int max_gran = BIN_MAX_LEAVES >> gran_shift;
+    // where a key's run starts
+    unsigned long long key[PER];
+    bool first[PER];
+    unsigned long long prev_key = 0;
+    if (g0 > 0 && g0 <= ngran) prev_key = (e - gran_cnt[g0 - 1]) / target;
+    unsigned long long last_start = 0;                       // (granule number + 1 of the last run start among this thread's)
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+        key[j] = e / target;
+        first[j] = g0 + j < ngran && (g0 + j == 0 || key[j] != prev_key);
+        if (first[j]) last_start = (unsigned long long)(g0 + j) + 1ull;
+        prev_key = key[j];
+        e += c[j];
+    }
+    unsigned long long unused;
+    unsigned long long run0 = scan(last_start, true, unused); // the last run start before this thread's granules (+ 1)
+    // pieces of at most max_gran granules
+    bool start[PER];
+    unsigned long long nstart = 0;
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+        if (first[j]) run0 = (unsigned long long)(g0 + j) + 1ull;
+        start[j] = g0 + j < ngran && (first[j] || ((unsigned long long)(g0 + j) + 1ull - run0) % (unsigned long long)max_gran == 0);
+        nstart += start[j] ? 1ull : 0ull;
+    }
+    unsigned long long nbins;
+    unsigned long long bin = scan(nstart, false, nbins);     // bins that start before this thread's granules
+    const bool fits = nbins > 0 && nbins <= (unsigned long long)BIN_MAX;
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+        if (g0 + j >= ngran) break;
+        if (start[j]) {
+            if (fits) s_lo[bin] = (uint32_t)(g0 + j) << gran_shift;
+            bin++;
+        }
+        // (bin is now this granule's bin + 1)
+        bin_map[g0 + j] = (uint16_t)(fits ? bin - 1 : 0);
+        if (fits && c[j]) atomicAdd(&s_pairs[bin - 1], c[j]);
     }
     __syncthreads();
-    const int nb = s_nb;
-    for (int g = tid; g < ngran; g += 1024) bin_map[g] = s_map[g];
-    for (int i = tid; i <= nb && nb > 0; i += 1024) bin_lo[i] = s_lo[i];
+    const int nb = fits ? (int)nbins : 0;
+    const unsigned long long cap = tid < nb ? 2ull * s_pairs[tid] + 1024ull : 0ull;
+    unsigned long long total_cap;
+    const unsigned long long off = scan(cap, false, total_cap);
+    if (tid < nb) {
+        bin_cap[tid] = (uint32_t)min(cap, 0xffffffffull);
+        bin_off[tid] = (uint32_t)min(off, 0xffffffffull);
+        bin_lo[tid] = s_lo[tid];
+    }
+    if (tid == 0) {
+        if (nb > 0) bin_lo[nb] = (uint32_t)nl;
+        info[0] = total_cap;
+        info[1] = (unsigned long long)nb;
+    }
 }
 
 void launch_bin_seed(const uint32_t *lq_cnt, int64_t nl, int32_t gran_shift, int32_t ngran, uint32_t *gran_cnt, uint16_t *bin_map,

@@ -24,11 +24,13 @@ target = max(int(gran.sum()) // 224, 1024)
 if target > 32000:                     # (half of what k_bin_lists stages in LDS, unless that made more than about 700 bins)
     target = max(32000, int(gran.sum()) // 700)
 max_gran = 8192 >> shift
-bins, acc, n_in = [], 0, 0
-for c in gran:
-    if n_in > 0 and (acc + c > target or n_in == max_gran):
+excl = np.concatenate([[0], np.cumsum(gran)[:-1]])
+key = excl // target                    # granules with one key form a run; a run is cut every max_gran granules
+bins, acc, n_in, prev = [], 0, 0, None
+for c, kx in zip(gran, key):
+    if n_in > 0 and (kx != prev or n_in == max_gran):
         bins.append((acc, n_in)); acc = 0; n_in = 0
-    acc += int(c); n_in += 1
+    acc += int(c); n_in += 1; prev = kx
 if n_in:
     bins.append((acc, n_in))
 pairs = np.array([b[0] for b in bins]); grans = np.array([b[1] for b in bins])
