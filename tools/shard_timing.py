@@ -1,7 +1,8 @@
 """Per-rank batch time of a sharded handle on one GPU (collectives excluded):
-python tools/shard_timing.py <mode: tables|rows> <shard groups> [workload] [query groups] [seed sample]
+python tools/shard_timing.py <mode: tables|rows> <shard groups> [workload] [query groups] [seed sample] [in flight: 1|2]
 times the rank that holds the largest shard (most tables / most rows) on its share of the queries, rotating
-through four distinct query batches."""
+through four distinct query batches.  In flight 2: a second handle over the same shard, a host thread and a stream each,
+the batches alternating between them (what a rank gains when one batch's small kernels run beside the other's scan)."""
 import os
 import sys
 import time
@@ -20,6 +21,7 @@ sg = int(sys.argv[2])
 wl = sys.argv[3] if len(sys.argv) > 3 else "c3"
 qg = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 seed_sample = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+in_flight = int(sys.argv[6]) if len(sys.argv) > 6 else 1
 n_base, n_q = (1250000, 12500) if wl == "c5" else (1000000, 10000)
 params, X, Q, pick, steps = bench.workload(wl, n_base, n_q)
 L = num_tables_of(params)
@@ -56,3 +58,33 @@ ms = (time.perf_counter() - t0) / n * 1e3
 st = ix.stats()
 print("%s %s: query groups %d x shard groups %d: %s, %d queries: %.3f ms per batch, forwarded %.0f per query, path %d" % (
     wl, mode, qg, sg, what, nq, ms, st["last_forwarded"] / nq, st["last_path"]), flush=True)
+
+if in_flight == 2:
+    import threading
+    other = DpfIndex(params, metric="l2", top_k=10, dtype=np.float32, device=0, **kw)
+    if seed_sample:
+        other.set_option("seed_sample", seed_sample)
+    other.fit(X)
+    handles = [ix, other]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    outs = [(torch.empty_like(d_ids), torch.empty_like(d_sc)) for _ in range(2)]
+
+    def worker(w, count):
+        torch.cuda.set_device(0)
+        for i in range(count):
+            q_, p_ = dB[(2 * i + w) % 4]
+            handles[w].query_topk_device(p_.data_ptr(), q_.data_ptr(), nq, steps, k, outs[w][0].data_ptr(), outs[w][1].data_ptr(),
+                                         streams[w].cuda_stream)
+        streams[w].synchronize()
+
+    for count in (4, 20):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        th = [threading.Thread(target=worker, args=(w, count)) for w in range(2)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t0
+    print("%s %s: query groups %d x shard groups %d: two batches in flight (two handles): %.3f ms per batch" % (wl, mode, qg, sg, dt2 / 40 * 1e3), flush=True)
