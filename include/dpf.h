@@ -371,7 +371,8 @@ enum {
                                         undecided rows; same hashes bit for bit); others by the exact vector-ALU kernel alone.
                                         Default 4096; 0 = never; 1 = always, whatever the shape */
     DPF_OPT_SCAN_PASSES = 8,         /* slices the scan's work units are run in, thresholds refined in between: 2, 3, or
-                                        0 = 3 for rows of 16 steps of 32 dimensions and more, 2 otherwise */
+                                        0 = 3 for rows of 16 steps of 32 dimensions and more and for forests whose seed sample
+                                        comes out at 1024 or more (a query's own buckets hold tens of thousands of rows), 2 otherwise */
     DPF_OPT_EARLY_PASS_PERMILLE = 9, /* with 3 passes: share of the units in the first of them (40) */
     DPF_OPT_EXACT_SEEDS = 10,        /* 1: l2 handles score the seed sample exactly from the fp32 rows, as dot handles do
                                         (default 0: an upper bound of the k-th best distance from the fp16 copies) */

@@ -1612,7 +1612,11 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
     // Slices of the units with the thresholds refined from what has been forwarded in between: a first 15 %, then the
     // rest; for long rows (one wave per SIMD: nothing hides the cost of a forwarded row) a fiftieth goes before them.
     const int first_permille = ix->opt_first_permille;
-    const int passes = ix->opt_scan_passes ? ix->opt_scan_passes : (ix->ks16 >= 16 ? 3 : 2);
+    // (three also where the query's own buckets hold so many rows that the seed sample - 1024 and more by the rule of
+    // seed_sample_for - is a small part of them: the first radii are then loose, and a refinement after a twenty-fifth of
+    // the units pays: 30 trees over SIFT-shaped rows, buckets of up to 31 k rows, 2.41 -> 2.30 ms per batch with 354 instead
+    // of 642 rows forwarded per query; 30 trees of 100-d clustered rows, sample 384: 2.39 -> 2.43 ms, left at two)
+    const int passes = ix->opt_scan_passes ? ix->opt_scan_passes : (ix->ks16 >= 16 || ix->auto_seed_cap >= 1024 ? 3 : 2);
     // A batch of few units (a single-table forest: a dozen units per wave) gains nothing from a refinement that costs
     // two more launches: one slice.  Judged by this batch's count when the host has read it, by the last batch's otherwise.
     const int64_t units_hint = carried ? ix->prev_units : nunits;
