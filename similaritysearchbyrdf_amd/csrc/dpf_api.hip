@@ -1704,7 +1704,8 @@ static int run_topk_bucket_major(dpf_index *ix, const int32_t *d_qids, const voi
                        ix->ws_emit.as<int32_t>(), d_ids, d_scores);
     rp.cand_stride = EMIT_CAP;
     if (ix->profiling) HIPCHECK(ix, hipEventRecord(ix->ev[4], stream));
-    if (short_lists && rerank_short_applies(rp)) launch_rerank_short(ix->cfg.dtype, ix->cfg.metric, rp, nq, stream);
+    // (deduplicated and pruned, the lists are a few tens of rows long)
+    if (short_lists && rerank_short_applies(rp)) launch_rerank_short(ix->cfg.dtype, ix->cfg.metric, rp, nq, stream, dedupe && !ix->opt_keep_forwarded);
     else launch_rerank(ix->cfg.dtype, ix->cfg.metric, rp, nq, stream);
     if (ix->profiling) HIPCHECK(ix, hipEventRecord(ix->ev[5], stream));
     HIPCHECK(ix, hipGetLastError());

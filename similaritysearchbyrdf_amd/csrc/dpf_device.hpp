@@ -296,7 +296,8 @@ void launch_compact(const int32_t *src, const int64_t *src_off, const int32_t *c
 void launch_rerank(int dtype, int metric, const RerankParams &p, int64_t nq, hipStream_t stream);
 int rerank_max_chunks16();
 bool rerank_short_applies(const RerankParams &p);
-void launch_rerank_short(int dtype, int metric, const RerankParams &p, int64_t nq, hipStream_t stream);
+// few_rows: the lists hold a few tens of rows (rows of more than 256 bytes are then scored 8 at a time per wave, not 32)
+void launch_rerank_short(int dtype, int metric, const RerankParams &p, int64_t nq, hipStream_t stream, bool few_rows = false);
 void launch_merge_topk(int metric, const int32_t *in_ids, const double *in_scores, int parts, int64_t ids_stride,
                        int64_t scores_stride, int64_t nq, int k, int32_t *out_ids, double *out_scores, hipStream_t stream);
 void launch_copy_rows(int dtype, const void *src, int64_t n, int dim, void *dst, int64_t dst_stride,
